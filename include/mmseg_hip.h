@@ -1,0 +1,146 @@
+/*
+ * mmseg_hip.h -- C ABI of libmmseg_hip.so, the gfx950 (MI355X / CDNA4) kernel library behind the
+ * DAFNet / MMSDNet training step.
+ *
+ * The reference (agis85/multimodal_segmentation) has no FFI of its own: its arithmetic lives in Keras 2.1.6 /
+ * TensorFlow 1.4 ops reached through the Python layer API.  Each entry point below replaces the TF op(s) that
+ * the cited reference line instantiates; the Python host code in multimodal_segmentation_amd/ binds them with
+ * ctypes (multimodal_segmentation_amd/_native.py) -- the binding a maintainer of the reference would add is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all tensors are dense fp32, NHWC, in device (HBM) memory; the caller owns every buffer (outputs and
+ *     workspaces are allocated by the caller; *_workspace_floats() tell how much); no allocation, no
+ *     synchronisation and no host<->device copy happens inside any entry point, so all of them may be
+ *     captured into a hipGraph;
+ *   - `stream` is a hipStream_t passed as void*; every launch goes to that stream;
+ *   - the return value is a hipError_t as int (0 = hipSuccess); invalid geometry returns hipErrorInvalidValue
+ *     without launching anything;
+ *   - reductions are two-stage and run in a fixed order: results are bitwise reproducible run to run
+ *     (exception: mmseg_tps_warp_bwd's d_vol uses float atomics).
+ */
+#ifndef MMSEG_HIP_H
+#define MMSEG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation codes */
+#define MMSEG_ACT_NONE 0
+#define MMSEG_ACT_RELU 1
+#define MMSEG_ACT_LEAKY 2
+#define MMSEG_ACT_TANH 3
+
+/* ---- convolution family (csrc/conv.hip): keras Conv2D [+UpSampling2D] [+Concatenate] -----------------------
+ * reference: models/unet.py:94-101, utils/model_utils.py:15-22, model_components/segmentor.py:16-24,
+ * modality_encoder.py:36-45, decoder.py:28,45-48, layers/spade.py:9-33, layers/stn_spline.py:106-114,
+ * models/discriminator.py:24,39.
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32.  Logical input [B,H,W,C1+C2] = concat(x1 (optionally stored at
+ * H/2 x W/2 and nearest-upsampled: ups=1), x2); kernel w [KH,KW,C1+C2,Cout] (keras HWIO); output [B,Ho,Wo,Cout].
+ * transposed=1 selects the fractionally-strided gather used for the data gradient of a strided convolution
+ * (tap valid iff (ho + kh - pad) % stride == 0).  y2/nsplit1: optional channel-split of the output
+ * (channels [0,nsplit1) -> y, the rest -> y2), used for the data gradient of a two-input convolution. */
+int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* bias, float* y, float* y2,
+                     int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                     int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, void* stream);
+long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
+/* dW[KH,KW,Cin,Cout] = sum over output pixels of im2col(x)^T * dy ; ws: mmseg_conv2d_wgrad_workspace floats */
+int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
+                       int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                       int pad_h, int pad_w, int ups, void* stream);
+/* wt[kh][kw][co][ci] = w[KH-1-kh][KW-1-kw][ci][co]: the kernel of the data-gradient convolution */
+int mmseg_conv2d_wflip(const float* w, float* wt, int KH, int KW, int Cin, int Cout, void* stream);
+
+/* ---- element-wise and small reductions (csrc/pointwise.hip) --------------------------------------------- */
+int mmseg_act_fwd(const float* x, float* y, long n, int act, float alpha, void* stream);
+/* dx = dy * act'(.) evaluated from the activation OUTPUT y */
+int mmseg_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float alpha, void* stream);
+int mmseg_axpby(const float* a, const float* b, float* out, long n, float sa, float sb, void* stream);
+int mmseg_fill(float* x, long n, float v, void* stream);
+int mmseg_colsum_blocks(long M);
+/* out[c] (+)= scale * sum_m x[m][c]; ws: mmseg_colsum_blocks(M)*C floats.  (bias gradients) */
+int mmseg_colsum(const float* x, float* out, float* ws, long M, int C, float scale, int accumulate, void* stream);
+/* keras MaxPooling2D(2) (models/unet.py:39-51, layers/stn_spline.py:108,111) */
+int mmseg_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int mmseg_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+/* gradient of keras UpSampling2D(2): dx[B,H,W,C] = 2x2 block sums of dy[B,2H,2W,C] */
+int mmseg_upsample2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+/* channel softmax; s (optional) = round-half-even(p): conv_anatomy softmax + layers/rounding.py:23-42 */
+int mmseg_softmax_fwd(const float* x, float* p, float* s, long npix, int C, void* stream);
+int mmseg_softmax_bwd(const float* dy, const float* p, float* dx, long npix, int C, void* stream);
+/* layers/film.py:26-36 fused with the LeakyReLU and residual Add of decoder.py:50-53: y = leaky(x*g+b) [+ res] */
+int mmseg_film_fwd(const float* x, const float* gamma, const float* beta, const float* res, float* y, int B, long HW, int C,
+                   float alpha, void* stream);
+int mmseg_film_bwd_workspace(int B, int C);
+int mmseg_film_bwd(const float* du, const float* x, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                   float* ws, int B, long HW, int C, float alpha, void* stream);
+/* keras Maximum (model_components/anatomy_fuser.py:33); gradient ties go to the first argument (tf.maximum) */
+int mmseg_maximum_fwd(const float* a, const float* b, float* y, long n, void* stream);
+int mmseg_maximum_bwd(const float* a, const float* b, const float* dy, float* da, float* db, long n, void* stream);
+/* Lambda x[..., c0:c0+Cs] (models/dafnet.py:187) */
+int mmseg_slice_fwd(const float* x, float* y, long M, int C, int c0, int Cs, void* stream);
+int mmseg_slice_bwd(const float* dy, float* dx, long M, int C, int c0, int Cs, void* stream);
+/* utils/sdnet_utils.py:9-21 (eps explicit) + costs.py:186-189 */
+int mmseg_sampling_kl_fwd(const float* mu, const float* lv, const float* eps, float* z, float* kl, int B, int Z, void* stream);
+int mmseg_sampling_kl_bwd(const float* mu, const float* lv, const float* eps, const float* dz, const float* dkl, float* dmu,
+                          float* dlv, int B, int Z, void* stream);
+
+/* ---- normalisation (csrc/norm.hip) ------------------------------------------------------------------- */
+int mmseg_norm_workspace_floats(int C);
+/* keras BatchNormalization, training: batch statistics; updates moving stats in place when non-null */
+int mmseg_bn_stats(const float* x, const float* gamma, const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                   float* mov_mean, float* mov_var, float* ws, long M, int C, float eps, float momentum, void* stream);
+int mmseg_bn_infer_prep(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float* scale, float* shift,
+                        int C, float eps, void* stream);
+int mmseg_bn_apply(const float* x, const float* scale, const float* shift, float* y, long M, int C, int relu, void* stream);
+int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean, const float* invstd,
+                 float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, void* stream);
+/* keras_contrib InstanceNormalization(axis=None) fused with SPADE_COND and LeakyReLU (layers/spade.py:7-33,51-54) */
+int mmseg_in_workspace_floats(int B);
+int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float* ws, int B,
+                             long per_sample, float eps, float act_alpha, void* stream);
+int mmseg_instnorm_spade_bwd(const float* dy, const float* x, const float* stat, const float* gamma, const float* beta, float* dx,
+                             float* dgamma, float* dbeta, float* dxn, float* ws, int B, long per_sample, float eps, float act_alpha,
+                             void* stream);
+
+/* ---- keras Dense for rows <= 32 (csrc/dense.hip) ----------------------------------------------------- */
+long mmseg_dense_workspace_floats(int R, int K, int N);
+int mmseg_dense_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int R, int K, int N, int act,
+                    float alpha, void* stream);
+int mmseg_dense_dgrad(const float* dy, const float* w, float* dx, int R, int K, int N, void* stream);
+int mmseg_dense_wgrad(const float* x, const float* dy, float* dw, int R, int K, int N, void* stream);
+
+/* ---- thin-plate-spline warp (csrc/tps.hip): layers/stn_spline.py:36-67 + interpolate_spline.py + resampler --- */
+int mmseg_tps_workspace_floats(int B);
+int mmseg_tps_warp_fwd(const float* vol, const float* theta, const float* Mb, float* out, float* loc, int B, int H, int W, int C,
+                       void* stream);
+int mmseg_tps_warp_bwd(const float* vol, const float* loc, const float* Mb, const float* dout, float* dvol, float* dtheta, float* dloc,
+                       float* ws, int B, int H, int W, int C, void* stream);
+
+/* ---- losses (csrc/loss.hip): costs.py:43-85,129-136, keras mae/mse, costs.ypred ---------------------------- */
+int mmseg_segloss_workspace_floats(int B);
+int mmseg_segloss_stats_floats(int B);
+int mmseg_segloss_coef_floats(int B, int C);
+int mmseg_segloss_class_offset(int B);
+int mmseg_segloss_stats(const float* pred, const float* target, float* stats, float* ws, int B, long HW, int C, int nm, void* stream);
+int mmseg_segloss_finalize(const float* stats, float* loss, float* coef, int B, int C, float n_pix_global, float lambda_bce, void* stream);
+int mmseg_segloss_grad(const float* pred, const float* target, const float* coef, float* dpred, int B, long HW, int C, int nm,
+                       float scale, int use_bce, void* stream);
+int mmseg_diffloss_workspace_floats(void);
+/* mode 0: mean|p-t|, 1: mean (p-t)^2, 2: mean p ; t == NULL -> constant target tconst */
+int mmseg_diffloss(const float* p, const float* t, float tconst, long n, int mode, float* loss, float* ws, void* stream);
+int mmseg_diffloss_grad(const float* p, const float* t, float tconst, long n, int mode, float scale, float* dp, void* stream);
+
+/* ---- optimiser / regulariser (csrc/optim.hip) ---------------------------------------------------------- */
+/* Keras 2.1.6 Adam step over a flat arena (models/dafnet.py:93,114,155,161) */
+int mmseg_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, void* stream);
+/* layers/spectralnorm.py:199-239 */
+long mmseg_spectral_workspace_floats(int K, int N);
+int mmseg_spectral_fwd(const float* w, const float* u0, float* loss, float* sgn, float* ws, int K, int N, float alpha, void* stream);
+int mmseg_spectral_grad(const float* w, const float* sgn, float scale, long n, float* dw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMSEG_HIP_H */

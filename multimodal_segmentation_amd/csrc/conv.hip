@@ -1,0 +1,534 @@
+// NHWC convolution family for gfx950 as implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD).
+//
+//   forward : y[m, n]  = act( sum_k A[m, k] * W[k, n] + bias[n] )      m = (b, ho, wo), k = (kh, kw, ci)
+//   dgrad   : the same kernel on flipped/transposed weights (mmseg_conv2d_wflip), with the
+//             fractionally-strided gather (`transposed`) for stride > 1
+//   wgrad   : dW[k, n] = sum_m A[m, k] * dy[m, n]  split over pixel chunks into slabs, then a
+//             deterministic slab reduction (no float atomics -> bitwise reproducible)
+//
+// The im2col matrix A is never materialised: each workgroup gathers its [BM x 32] tile from the
+// NHWC activation straight into LDS (16-byte loads along the channel axis).  The gather also
+// folds nearest x2 up-sampling of the input (keras UpSampling2D before a conv) and the channel
+// concatenation of two inputs (keras Concatenate before a conv), so neither is ever written
+// to HBM.  Reference ops replaced: keras Conv2D / UpSampling2D / Concatenate as used in
+// models/unet.py:37-101, utils/model_utils.py:15-22, model_components/*.py,
+// models/discriminator.py:16-41, layers/stn_spline.py:94-120 of the reference.
+//
+// LDS tile layout: As[m][k] (k contiguous, row stride 36 floats -> conflict-free ds_read_b128),
+// Bs[k][n].  The K index inside an 8-wide chunk is permuted (lane half h owns k = 8q+4h+t) so one
+// ds_read_b128 feeds four consecutive MFMAs; A and B use the same permutation so the sum is
+// unchanged.
+#include "common.hpp"
+
+struct ConvParams {
+    const float* x1;
+    const float* x2;
+    const float* w;
+    const float* bias;
+    float* y;
+    float* y2;      // second output for channel-split epilogue (dgrad of a concat conv) or nullptr
+    int B, H, W;    // logical input spatial size (after optional up-sampling)
+    int C1, C2;     // channels taken from x1 / x2 (C2 = 0: single input)
+    int H1, W1;     // physical spatial size of x1 (H >> ups, W >> ups)
+    int Ho, Wo, Cout;
+    int KH, KW, stride, pad_h, pad_w;
+    int ups;        // x1 is stored at half resolution and nearest-upsampled on the fly
+    int transposed; // fractionally strided gather: tap valid iff (ho + kh - pad) % stride == 0
+    int act;
+    float alpha;
+    int M, K;
+    int nsplit1;    // channel split point of the epilogue (Cout1) when y2 != nullptr
+};
+
+#define BK 32
+#define AS_LD (BK + 4)
+
+__device__ __forceinline__ f32x4 gather_tap4(const ConvParams& p, int b, int hb, int wb, int kh, int kw, int c) {
+    // returns 4 consecutive channels c..c+3 of the (possibly virtual) input at the tap, or zeros
+    int hi = hb + kh, wi = wb + kw;
+    if (p.transposed) {
+        if (hi < 0 || wi < 0) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const int s = p.stride;
+        const int hq = hi / s, wq = wi / s;
+        if (hq * s != hi || wq * s != wi) return f32x4{0.f, 0.f, 0.f, 0.f};
+        hi = hq; wi = wq;
+    }
+    if ((unsigned)hi >= (unsigned)p.H || (unsigned)wi >= (unsigned)p.W) return f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* src;
+    if (c < p.C1) {
+        const int h1 = p.ups ? (hi >> 1) : hi, w1 = p.ups ? (wi >> 1) : wi;
+        src = p.x1 + (((size_t)b * p.H1 + h1) * p.W1 + w1) * p.C1 + c;
+    } else {
+        src = p.x2 + (((size_t)b * p.H + hi) * p.W + wi) * p.C2 + (c - p.C1);
+    }
+    return *reinterpret_cast<const f32x4*>(src);
+}
+
+__device__ __forceinline__ float gather_tap1(const ConvParams& p, int b, int hb, int wb, int kh, int kw, int c) {
+    int hi = hb + kh, wi = wb + kw;
+    if (p.transposed) {
+        if (hi < 0 || wi < 0) return 0.f;
+        const int s = p.stride;
+        const int hq = hi / s, wq = wi / s;
+        if (hq * s != hi || wq * s != wi) return 0.f;
+        hi = hq; wi = wq;
+    }
+    if ((unsigned)hi >= (unsigned)p.H || (unsigned)wi >= (unsigned)p.W) return 0.f;
+    if (c < p.C1) {
+        const int h1 = p.ups ? (hi >> 1) : hi, w1 = p.ups ? (wi >> 1) : wi;
+        return p.x1[(((size_t)b * p.H1 + h1) * p.W1 + w1) * p.C1 + c];
+    }
+    return p.x2[(((size_t)b * p.H + hi) * p.W + wi) * p.C2 + (c - p.C1)];
+}
+
+// gather 4 consecutive k (k..k+3) of im2col row (b, hb, wb)
+template <bool VEC>
+__device__ __forceinline__ f32x4 gather_a(const ConvParams& p, int b, int hb, int wb, int k, int tap, int c) {
+    if (VEC) {
+        if (k >= p.K) return f32x4{0.f, 0.f, 0.f, 0.f};
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        return gather_tap4(p, b, hb, wb, kh, kw, c);
+    } else {
+        f32x4 v;
+        const int Cin = p.C1 + p.C2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ke = k + e;
+            float t = 0.f;
+            if (ke < p.K) {
+                const int tp = ke / Cin, ce = ke - tp * Cin;
+                const int kh = tp / p.KW, kw = tp - kh * p.KW;
+                t = gather_tap1(p, b, hb, wb, kh, kw, ce);
+            }
+            v[e] = t;
+        }
+        return v;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_ROWS_PER_PASS = NT / 8;
+    constexpr int A_F4 = BM / A_ROWS_PER_PASS;
+    constexpr int BF4_PER_ROW = BN / 4;
+    constexpr int B_ROWS_PER_PASS = NT / BF4_PER_ROW;
+    constexpr int B_F4 = (BK + B_ROWS_PER_PASS - 1) / B_ROWS_PER_PASS;
+    constexpr int BS_LD = BN + 4;
+    static_assert(A_F4 >= 1 && BM % A_ROWS_PER_PASS == 0, "A staging");
+
+    __shared__ __attribute__((aligned(16))) float As[BM * AS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BS_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // block -> (m tile, n tile); n fastest so that the blocks of one XCD share the A panel in L2
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    const int lb = xcd_remap(blockIdx.x, nwg);
+    const int m0 = (lb / ntn) * BM, n0 = (lb % ntn) * BN;
+
+    // ---- per-thread A gather state -------------------------------------------------------
+    const int kc = tid & 7;              // which float4 of the 32-wide K tile
+    const int ar0 = tid >> 3;            // first row
+    int a_b[A_F4], a_hb[A_F4], a_wb[A_F4];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) {
+        const int m = m0 + ar0 + j * A_ROWS_PER_PASS;
+        if (m < p.M) {
+            const int b = m / HoWo, r = m - b * HoWo;
+            const int ho = r / p.Wo, wo = r - ho * p.Wo;
+            a_b[j] = b;
+            a_hb[j] = (p.transposed ? ho : ho * p.stride) - p.pad_h;
+            a_wb[j] = (p.transposed ? wo : wo * p.stride) - p.pad_w;
+        } else {
+            a_b[j] = 0; a_hb[j] = -(1 << 28); a_wb[j] = -(1 << 28);  // every tap out of range -> zeros
+        }
+    }
+    const int Cin = p.C1 + p.C2;
+    int a_k = 4 * kc, a_tap = 0, a_c = 4 * kc;
+    if (VEC) { a_tap = a_k / Cin; a_c = a_k - a_tap * Cin; }
+
+    // ---- per-thread B (weight) load state -------------------------------------------------
+    const int b_nc = tid % BF4_PER_ROW, b_r0 = tid / BF4_PER_ROW;
+    const bool w_vec = (p.Cout & 3) == 0;
+
+    f32x4 ra[A_F4], rb[B_F4];
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) ra[j] = gather_a<VEC>(p, a_b[j], a_hb[j], a_wb[j], a_k, a_tap, a_c);
+        a_k += BK;
+        if (VEC) { a_c += BK; while (a_c >= Cin) { a_c -= Cin; ++a_tap; } }
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) {
+            const int kr = b_r0 + j * B_ROWS_PER_PASS;
+            const int k = kt * BK + kr, n = n0 + 4 * b_nc;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kr < BK && k < p.K) {
+                const float* src = p.w + (size_t)k * p.Cout + n;
+                if (w_vec) {
+                    if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.Cout) v[e] = src[e];
+                }
+            }
+            rb[j] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j)
+            *reinterpret_cast<f32x4*>(&As[(ar0 + j * A_ROWS_PER_PASS) * AS_LD + 4 * kc]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) {
+            const int kr = b_r0 + j * B_ROWS_PER_PASS;
+            if (kr < BK) *reinterpret_cast<f32x4*>(&Bs[kr * BS_LD + 4 * b_nc]) = rb[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    const int a_row = wm * (BM / WM) + li;
+    const int b_col = wn * (BN / WN) + li;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tile(kt + 1);   // global loads stay in flight under the MFMAs
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(&As[(a_row + i * 32) * AS_LD + 8 * q + 4 * lh]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float b[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bs[(8 * q + 4 * lh + t) * BS_LD + b_col + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias + activation, rows of 32 consecutive channels per half-wave ---------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + li;
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                const float v = act_apply(acc[i][j][r] + bv, p.act, p.alpha);
+                if (p.y2 == nullptr) p.y[(size_t)m * p.Cout + n] = v;
+                else if (n < p.nsplit1) p.y[(size_t)m * p.nsplit1 + n] = v;
+                else p.y2[(size_t)m * (p.Cout - p.nsplit1) + (n - p.nsplit1)] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
+    dim3 grid(ntm * ntn), block(WM * WN * 64);
+    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, p);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+static int conv_dispatch(ConvParams& p, hipStream_t st) {
+    if (p.M <= 0 || p.Cout <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
+    const bool vec = (p.C1 % 4 == 0) && (p.C2 % 4 == 0) && aligned16(p.x1) && (p.C2 == 0 || aligned16(p.x2));
+    const long tiles_big = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    if (p.Cout > 64 && tiles_big >= 384) return launch_fwd<128, 128, 2, 2>(p, vec, st);
+    if (p.Cout > 32) {
+        const long tiles_mid = (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
+        if (tiles_mid >= 384) return launch_fwd<128, 64, 2, 2>(p, vec, st);
+        return launch_fwd<64, 64, 2, 2>(p, vec, st);
+    }
+    return launch_fwd<128, 32, 4, 1>(p, vec, st);
+}
+
+// =====================================================================================
+// wgrad: dW[k, n] = sum_m A[m, k] dy[m, n]
+// =====================================================================================
+struct WgradParams {
+    ConvParams c;       // geometry + x1/x2 (gather source); c.y unused
+    const float* dy;    // [M, Cout]
+    float* ws;          // [S, K, Cout] slabs (or dW itself when S == 1)
+    int chunk;          // pixels per split (multiple of 32)
+};
+
+template <int BKT, int BNT, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(WgradParams q) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BKT / WM / 32, TN = BNT / WN / 32;
+    constexpr int PT = 32;                       // pixels per LDS stage
+    constexpr int AF4_PER_ROW = BKT / 4, A_RPP = NT / AF4_PER_ROW, A_F4 = (PT + A_RPP - 1) / A_RPP;
+    constexpr int DF4_PER_ROW = BNT / 4, D_RPP = NT / DF4_PER_ROW, D_F4 = (PT + D_RPP - 1) / D_RPP;
+    const ConvParams& p = q.c;
+
+    __shared__ __attribute__((aligned(16))) float Ap[PT * BKT];
+    __shared__ __attribute__((aligned(16))) float Dp[PT * BNT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int k0 = blockIdx.x * BKT, n0 = blockIdx.y * BNT;
+    const int pbeg = blockIdx.z * q.chunk;
+    const int pend = min(p.M, pbeg + q.chunk);
+
+    // A gather: this thread always fetches the same 4 k's (fixed tap / channel), rows advance
+    const int a_kc = tid % AF4_PER_ROW, a_r0 = tid / AF4_PER_ROW;
+    const int a_k = k0 + 4 * a_kc;
+    const int Cin = p.C1 + p.C2;
+    int a_tap = 0, a_c = 0;
+    if (VEC) { a_tap = a_k / Cin; a_c = a_k - a_tap * Cin; }
+    int r_b[A_F4], r_ho[A_F4], r_wo[A_F4];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) {
+        const int m = pbeg + a_r0 + j * A_RPP;
+        const int b = m / HoWo, r = m - b * HoWo;
+        r_b[j] = b; r_ho[j] = r / p.Wo; r_wo[j] = r - r_ho[j] * p.Wo;
+    }
+    const int d_nc = tid % DF4_PER_ROW, d_r0 = tid / DF4_PER_ROW;
+    const bool dy_vec = (p.Cout & 3) == 0;
+
+    f32x4 ra[A_F4], rd[D_F4];
+    auto load_stage = [&](int ps) {
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int pr = a_r0 + j * A_RPP;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pr < PT && ps + pr < pend) {
+                const int hb = r_ho[j] * p.stride - p.pad_h, wb = r_wo[j] * p.stride - p.pad_w;
+                v = gather_a<VEC>(p, r_b[j], hb, wb, a_k, a_tap, a_c);
+            }
+            ra[j] = v;
+            // advance this row's pixel by PT
+            r_wo[j] += PT;
+            while (r_wo[j] >= p.Wo) { r_wo[j] -= p.Wo; if (++r_ho[j] >= p.Ho) { r_ho[j] = 0; ++r_b[j]; } }
+        }
+#pragma unroll
+        for (int j = 0; j < D_F4; ++j) {
+            const int pr = d_r0 + j * D_RPP;
+            const int m = ps + pr, n = n0 + 4 * d_nc;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pr < PT && m < pend) {
+                const float* src = q.dy + (size_t)m * p.Cout + n;
+                if (dy_vec) { if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(src); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.Cout) v[e] = src[e];
+                }
+            }
+            rd[j] = v;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int pr = a_r0 + j * A_RPP;
+            if (pr < PT) *reinterpret_cast<f32x4*>(&Ap[pr * BKT + 4 * a_kc]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D_F4; ++j) {
+            const int pr = d_r0 + j * D_RPP;
+            if (pr < PT) *reinterpret_cast<f32x4*>(&Dp[pr * BNT + 4 * d_nc]) = rd[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (pbeg < pend) {
+        load_stage(pbeg);
+        store_stage();
+        __syncthreads();
+        const int a_col = wm * (BKT / WM) + li, b_col = wn * (BNT / WN) + li;
+        for (int ps = pbeg; ps < pend; ps += PT) {
+            const bool more = ps + PT < pend;
+            if (more) load_stage(ps + PT);
+#pragma unroll
+            for (int s = 0; s < PT / 2; ++s) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = Ap[(2 * s + lh) * BKT + a_col + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Dp[(2 * s + lh) * BNT + b_col + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) { store_stage(); __syncthreads(); }
+        }
+    }
+
+    float* out = q.ws + (size_t)blockIdx.z * p.K * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BNT / WN) + j * 32 + li;
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * (BKT / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < p.K) out[(size_t)k * p.Cout + n] = acc[i][j][r];
+            }
+    }
+}
+
+// dW[i] = sum_s ws[s][i]   (fixed order -> deterministic)
+__global__ void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n, int S) {
+    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i4);
+        *reinterpret_cast<f32x4*>(out + i4) = a;
+    } else {
+        for (long i = i4; i < n; ++i) {
+            float a = 0.f;
+            for (int s = 0; s < S; ++s) a += ws[(size_t)s * n + i];
+            out[i] = a;
+        }
+    }
+}
+
+template <int BKT, int BNT, int WM, int WN>
+static int launch_wgrad(const WgradParams& q, int S, bool vec, hipStream_t st) {
+    dim3 grid((q.c.K + BKT - 1) / BKT, (q.c.Cout + BNT - 1) / BNT, S), block(WM * WN * 64);
+    if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<BKT, BNT, WM, WN, true>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BKT, BNT, WM, WN, false>), grid, block, 0, st, q);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+// flip + transpose: wt[kh][kw][co][ci] = w[KH-1-kh][KW-1-kw][ci][co]
+__global__ void wflip_kernel(const float* __restrict__ w, float* __restrict__ wt, int KH, int KW, int Cin, int Cout) {
+    __shared__ float t[32][33];
+    const int tap = blockIdx.z, kh = tap / KW, kw = tap % KW;
+    const float* src = w + (size_t)((KH - 1 - kh) * KW + (KW - 1 - kw)) * Cin * Cout;
+    float* dst = wt + (size_t)tap * Cin * Cout;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        t[r][tx] = (ci < Cin && co < Cout) ? src[(size_t)ci * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = t[tx][r];
+    }
+}
+
+extern "C" {
+
+// Geometry arrays are plain ints so the ABI stays free of C++ types (see include/mmseg_hip.h).
+int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* bias, float* y, float* y2,
+                     int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                     int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, void* stream) {
+    ConvParams p;
+    p.x1 = x1; p.x2 = x2; p.w = w; p.bias = bias; p.y = y; p.y2 = y2;
+    p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
+    p.H1 = ups ? H / 2 : H; p.W1 = ups ? W / 2 : W;
+    p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
+    p.pad_h = pad_h; p.pad_w = pad_w; p.ups = ups; p.transposed = transposed; p.act = act; p.alpha = alpha;
+    p.M = B * Ho * Wo; p.K = KH * KW * (C1 + C2); p.nsplit1 = nsplit1;
+    if (ups && ((H & 1) || (W & 1))) return (int)hipErrorInvalidValue;
+    if (C2 > 0 && x2 == nullptr) return (int)hipErrorInvalidValue;
+    if ((long)B * Ho * Wo >= (1L << 31)) return (int)hipErrorInvalidValue;
+    return conv_dispatch(p, (hipStream_t)stream);
+}
+
+// number of floats of workspace mmseg_conv2d_wgrad needs for this geometry (0: writes dW directly)
+long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+    const long M = (long)B * Ho * Wo, K = (long)KH * KW * Cin;
+    const long tiles = ((K + 127) / 128) * ((Cout + 63) / 64);
+    long S = (1024 + tiles - 1) / tiles;
+    const long maxS = (M + 511) / 512;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    return S == 1 ? 0 : S * K * Cout;
+}
+
+int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
+                       int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                       int pad_h, int pad_w, int ups, void* stream) {
+    WgradParams q;
+    ConvParams& p = q.c;
+    p.x1 = x1; p.x2 = x2; p.w = nullptr; p.bias = nullptr; p.y = nullptr; p.y2 = nullptr;
+    p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
+    p.H1 = ups ? H / 2 : H; p.W1 = ups ? W / 2 : W;
+    p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
+    p.pad_h = pad_h; p.pad_w = pad_w; p.ups = ups; p.transposed = 0; p.act = 0; p.alpha = 0.f;
+    p.M = B * Ho * Wo; p.K = KH * KW * (C1 + C2); p.nsplit1 = 0;
+    if (p.M <= 0 || p.K <= 0 || Cout <= 0) return (int)hipErrorInvalidValue;
+    const long need = mmseg_conv2d_wgrad_workspace(B, Ho, Wo, C1 + C2, Cout, KH, KW);
+    if (need > ws_floats) return (int)hipErrorInvalidValue;
+    const long KN = (long)p.K * Cout;
+    const int S = need == 0 ? 1 : (int)(need / KN);
+    int chunk = (p.M + S - 1) / S;
+    chunk = (chunk + 31) / 32 * 32;
+    q.dy = dy; q.chunk = chunk; q.ws = S == 1 ? dw : ws;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (C1 % 4 == 0) && (C2 % 4 == 0) && aligned16(x1) && (C2 == 0 || aligned16(x2));
+    int rc;
+    if (Cout > 32) rc = launch_wgrad<128, 64, 2, 2>(q, S, vec, st);
+    else rc = launch_wgrad<128, 32, 4, 1>(q, S, vec, st);
+    if (rc != 0 || S == 1) return rc;
+    const int threads = 256;
+    const long n4 = (KN + 3) / 4;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + threads - 1) / threads)), dim3(threads), 0, st,
+                       (const float*)ws, dw, KN, S);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_conv2d_wflip(const float* w, float* wt, int KH, int KW, int Cin, int Cout, void* stream) {
+    if (KH * KW > 65535) return (int)hipErrorInvalidValue;
+    dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, KH * KW);
+    hipLaunchKernelGGL(wflip_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, KH, KW, Cin, Cout);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// keras Dense for tiny batches (rows <= 32) on gfx950: GEMV-shaped and bound by streaming the weight
+// matrix once from HBM, so no MFMA (a 32-row MFMA tile would be >= 75 % padding).  Used by
+// model_components/modality_encoder.py:45-50, decoder.py:37-40,68, layers/stn_spline.py:115-116,
+// models/discriminator.py:32-33, model_components/balancer.py:24-25 of the reference.
+#include "common.hpp"
+
+#define DENSE_KSLICES_MAX 256
+
+static inline int dense_kslices(int K) {
+    int ks = (K + 511) / 512;
+    if (ks > DENSE_KSLICES_MAX) ks = DENSE_KSLICES_MAX;
+    if (ks < 1) ks = 1;
+    return ks;
+}
+
+// part[ks][b][n] = sum_{k in slice ks} x[b][k] * W[k][n]; block = 4 k-lanes x 64 n-lanes
+template <int RB>
+__global__ void dense_fwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
+                                         int R, int K, int N, int kper) {
+    __shared__ float red[4][RB][64];
+    const int nl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + nl;
+    const int kbeg = blockIdx.y * kper, kend = min(K, kbeg + kper);
+    float acc[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) acc[b] = 0.f;
+    if (n < N) {
+        for (int k = kbeg + kl; k < kend; k += 4) {
+            const float wv = w[(size_t)k * N + n];
+#pragma unroll
+            for (int b = 0; b < RB; ++b)
+                if (b < R) acc[b] += x[(size_t)b * K + k] * wv;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) red[kl][b][nl] = acc[b];
+    __syncthreads();
+    if (kl == 0 && n < N) {
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+            if (b < R) part[((size_t)blockIdx.y * R + b) * N + n] = red[0][b][nl] + red[1][b][nl] + red[2][b][nl] + red[3][b][nl];
+    }
+}
+
+__global__ void dense_fwd_final_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
+                                       int R, int N, int ks, int act, float alpha) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * N) return;
+    float t = 0.f;
+    for (int s = 0; s < ks; ++s) t += part[(size_t)s * R * N + i];
+    if (bias) t += bias[i % N];
+    y[i] = act_apply(t, act, alpha);
+}
+
+// dx[b][k] = sum_n dy[b][n] * W[k][n]; 64 rows of W per block staged through LDS in N-chunks of 128
+__global__ void dense_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                   int R, int K, int N) {
+    __shared__ float Ws[64 * 129];
+    __shared__ float Ds[32 * 128];
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * 64;
+    const int r = tid & 63, bg = tid >> 6;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int nb = 0; nb < N; nb += 128) {
+        const int nw = min(128, N - nb);
+        for (int i = tid; i < 64 * nw; i += 256) {
+            const int rr = i / nw, nn = i - rr * nw;
+            Ws[rr * 129 + nn] = (k0 + rr < K) ? w[(size_t)(k0 + rr) * N + nb + nn] : 0.f;
+        }
+        for (int i = tid; i < R * nw; i += 256) {
+            const int bb = i / nw, nn = i - bb * nw;
+            Ds[bb * 128 + nn] = dy[(size_t)bb * N + nb + nn];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = bg + 4 * i;
+            if (b < R) {
+                float a = 0.f;
+                for (int nn = 0; nn < nw; ++nn) a += Ds[b * 128 + nn] * Ws[r * 129 + nn];
+                acc[i] += a;
+            }
+        }
+        __syncthreads();
+    }
+    if (k0 + r < K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = bg + 4 * i;
+            if (b < R) dx[(size_t)b * K + k0 + r] = acc[i];
+        }
+    }
+}
+
+// dW[k][n] = sum_b x[b][k] * dy[b][n]
+__global__ void dense_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                   int R, int K, int N) {
+    const long total = (long)K * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i / N, n = i - (long)k * N;
+        float a = 0.f;
+        for (int b = 0; b < R; ++b) a += x[(size_t)b * K + k] * dy[(size_t)b * N + n];
+        dw[i] = a;
+    }
+}
+
+extern "C" {
+
+long mmseg_dense_workspace_floats(int R, int K, int N) { return (long)dense_kslices(K) * R * N; }
+
+int mmseg_dense_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int R, int K, int N, int act,
+                    float alpha, void* stream) {
+    if (R < 1 || R > 32) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int ks = dense_kslices(K);
+    const int kper = (K + ks - 1) / ks;
+    dim3 grid((N + 63) / 64, ks), block(256);
+    if (R <= 8) hipLaunchKernelGGL(dense_fwd_partial_kernel<8>, grid, block, 0, st, x, w, ws, R, K, N, kper);
+    else if (R <= 16) hipLaunchKernelGGL(dense_fwd_partial_kernel<16>, grid, block, 0, st, x, w, ws, R, K, N, kper);
+    else hipLaunchKernelGGL(dense_fwd_partial_kernel<32>, grid, block, 0, st, x, w, ws, R, K, N, kper);
+    hipLaunchKernelGGL(dense_fwd_final_kernel, dim3((R * N + 255) / 256), dim3(256), 0, st, (const float*)ws, bias, y, R, N, ks, act, alpha);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_dense_dgrad(const float* dy, const float* w, float* dx, int R, int K, int N, void* stream) {
+    if (R < 1 || R > 32) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(dense_dgrad_kernel, dim3((K + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, w, dx, R, K, N);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_dense_wgrad(const float* x, const float* dy, float* dw, int R, int K, int N, void* stream) {
+    if (R < 1 || R > 32) return (int)hipErrorInvalidValue;
+    long blocks = ((long)K * N + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dense_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dw, R, K, N);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+}  // extern "C"

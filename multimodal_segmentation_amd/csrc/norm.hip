@@ -1,0 +1,309 @@
+// BatchNorm (keras BatchNormalization, axis=-1, momentum .99, eps 1e-3) and InstanceNorm
+// (keras_contrib InstanceNormalization(axis=None, center=False, scale=False)) for NHWC fp32 on gfx950.
+// HBM-bound: every pass reads/writes each element once with 16-byte accesses; per-channel reductions are
+// two-stage (per-block partials in a workspace, then a tiny finalize) so results are run-to-run bitwise
+// reproducible.  Reference call sites: utils/model_utils.py:6-12, models/unet.py:94-101,
+// model_components/segmentor.py:16-21, layers/spade.py:27.
+#include "common.hpp"
+
+#define NORM_MAX_BLOCKS 1024
+
+static inline int norm_blocks(long M) {
+    long nb = (M + 511) / 512;
+    if (nb > NORM_MAX_BLOCKS) nb = NORM_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+// MODE 0: (x - shift, (x - shift)^2) with shift = x[0][c]      -> batch statistics
+// MODE 1: (g, g * xhat), g = dy * [y > 0 if relu], xhat = (x - mean) * invstd   -> BN backward sums
+template <int MODE>
+__global__ void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                  float* __restrict__ part, long M, int C, long rows_per_block, int relu) {
+    __shared__ float sm[2 * 256];
+    const int tid = threadIdx.x;
+    const int cw = min(C, 256), rl = 256 / cw;
+    const int c_in = tid % cw, r_in = tid / cw;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int cb = 0; cb < C; cb += cw) {
+        const int c = cb + c_in;
+        float s1 = 0.f, s2 = 0.f;
+        if (c < C && r_in < rl) {
+            if (MODE == 0) {
+                const float sh = x[c];
+                for (long r = r0 + r_in; r < r1; r += rl) { const float d = x[r * C + c] - sh; s1 += d; s2 += d * d; }
+            } else {
+                const float mu = mean[c], is = invstd[c];
+                for (long r = r0 + r_in; r < r1; r += rl) {
+                    float g = dy[r * C + c];
+                    if (relu && !(y[r * C + c] > 0.f)) g = 0.f;
+                    s1 += g; s2 += g * (x[r * C + c] - mu) * is;
+                }
+            }
+        }
+        sm[tid] = s1; sm[256 + tid] = s2;
+        __syncthreads();
+        if (tid < cw && c < C) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int k = 0; k < rl; ++k) { t1 += sm[k * cw + tid]; t2 += sm[256 + k * cw + tid]; }
+            part[((size_t)blockIdx.x * 2) * C + c] = t1;
+            part[((size_t)blockIdx.x * 2 + 1) * C + c] = t2;
+        }
+        __syncthreads();
+    }
+}
+
+// training statistics -> mean, invstd, fused scale/shift, moving-average update
+__global__ void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,
+                                      float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mov_mean,
+                                      float* __restrict__ mov_var, int nblk, int C, long M, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nblk; ++b) { s1 += part[((size_t)b * 2) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
+    const float invM = 1.f / (float)M;
+    const float d = s1 * invM;
+    const float mu = x[c] + d;
+    float var = s2 * invM - d * d;
+    var = var > 0.f ? var : 0.f;
+    const float is = rsqrtf(var + eps);
+    mean[c] = mu; invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc; shift[c] = beta[c] - mu * sc;
+    if (mov_mean) {
+        const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+        mov_mean[c] -= (mov_mean[c] - mu) * (1.f - momentum);
+        mov_var[c] -= (mov_var[c] - unb) * (1.f - momentum);
+    }
+}
+
+// inference: scale/shift from the moving statistics
+__global__ void bn_infer_prep_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mov_mean,
+                                     const float* __restrict__ mov_var, float* __restrict__ scale, float* __restrict__ shift,
+                                     int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(mov_var[c] + eps);
+    scale[c] = sc; shift[c] = beta[c] - mov_mean[c] * sc;
+}
+
+// y = x * scale[c] + shift[c]  (+ReLU)
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                float* __restrict__ y, long n4, int C4, int relu) {
+    const f32x4* S = reinterpret_cast<const f32x4*>(scale);
+    const f32x4* T = reinterpret_cast<const f32x4*>(shift);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i] * S[c] + T[c];
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+// finalize backward sums: dbeta, dgamma and per-channel coefficients  dx = A*g + Bc*x + Cc
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    float* __restrict__ coef /* [3][C] */, int nblk, int C, long M) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nblk; ++b) { s1 += part[((size_t)b * 2) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
+    dbeta[c] = s1; dgamma[c] = s2;
+    const float invM = 1.f / (float)M, is = invstd[c], ga = gamma[c], mu = mean[c];
+    const float A = ga * is;
+    const float Bc = -ga * is * is * s2 * invM;
+    coef[c] = A; coef[C + c] = Bc; coef[2 * C + c] = -A * s1 * invM - Bc * mu;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+                                    const float* __restrict__ coef, float* __restrict__ dx, long n4, int C4, int relu) {
+    const f32x4* A = reinterpret_cast<const f32x4*>(coef);
+    const f32x4* Bc = A + C4;
+    const f32x4* Cc = A + 2 * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        if (relu) {
+            const f32x4 o = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = A[c] * g + Bc[c] * reinterpret_cast<const f32x4*>(x)[i] + Cc[c];
+    }
+}
+
+// =====================================================================================================
+// InstanceNorm over (H, W, C) jointly per sample:  xn = (x - mean_b) / (std_b + eps)
+// fused SPADE modulation + LeakyReLU:  y = leaky( xn * (1 + gamma) + beta )      (layers/spade.py:7-33,51-54)
+// =====================================================================================================
+// per-sample sums: grid (nchunk, B): part[b][chunk][2] = (sum(x - x0), sum((x - x0)^2))
+__global__ void in_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long per_sample, int nchunk) {
+    __shared__ float red[17];
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * per_sample;
+    const float sh = xb[0];
+    const long per = (per_sample + nchunk - 1) / nchunk;
+    const long i0 = (long)blockIdx.x * per, i1 = min(per_sample, i0 + per);
+    float s1 = 0.f, s2 = 0.f;
+    for (long i = i0 + threadIdx.x; i < i1; i += blockDim.x) { const float d = xb[i] - sh; s1 += d; s2 += d * d; }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { part[((size_t)b * nchunk + blockIdx.x) * 2] = s1; part[((size_t)b * nchunk + blockIdx.x) * 2 + 1] = s2; }
+}
+__global__ void in_final_kernel(const float* __restrict__ part, const float* __restrict__ x, float* __restrict__ stat /* [B][2]: mean, 1/(std+eps) */,
+                                long per_sample, int nchunk, int B, float eps) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) { s1 += part[((size_t)b * nchunk + k) * 2]; s2 += part[((size_t)b * nchunk + k) * 2 + 1]; }
+    const float inv = 1.f / (float)per_sample;
+    const float d = s1 * inv;
+    float var = s2 * inv - d * d;
+    var = var > 0.f ? var : 0.f;
+    stat[2 * b] = x[(size_t)b * per_sample] + d;
+    stat[2 * b + 1] = 1.f / (sqrtf(var) + eps);
+}
+// y = act( (x - mean)*rstd * (1 + gamma) + beta ); gamma/beta nullptr -> plain normalisation. act_alpha<0: no activation
+__global__ void in_apply_kernel(const float* __restrict__ x, const float* __restrict__ stat, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ y, long per_sample, long n, float act_alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = i / per_sample;
+        float v = (x[i] - stat[2 * b]) * stat[2 * b + 1];
+        if (gamma) v = v * (1.f + gamma[i]) + beta[i];
+        if (act_alpha >= 0.f) v = v >= 0.f ? v : v * act_alpha;
+        y[i] = v;
+    }
+}
+// backward of the fused op.  With xn = (x-mean)*rstd, u = xn*(1+gamma)+beta, y = leaky(u):
+//   g = dy*leaky'(u); dgamma = g*xn; dbeta = g; dxn = g*(1+gamma)
+//   dx = rstd * ( dxn - mean_b(dxn) - xn * rstd*sqrt(var)... )  -- see in_bwd_final for the (std+eps) form
+// pass 1: elementwise dgamma/dbeta + per-sample sums S1 = sum dxn, S2 = sum dxn*xn
+__global__ void in_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stat,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, float* __restrict__ dxn_out, float* __restrict__ part,
+                                      long per_sample, int nchunk, float act_alpha) {
+    __shared__ float red[17];
+    const int b = blockIdx.y;
+    const size_t off = (size_t)b * per_sample;
+    const float mu = stat[2 * b], rs = stat[2 * b + 1];
+    const long per = (per_sample + nchunk - 1) / nchunk;
+    const long i0 = (long)blockIdx.x * per, i1 = min(per_sample, i0 + per);
+    float s1 = 0.f, s2 = 0.f;
+    for (long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const float xn = (x[off + i] - mu) * rs;
+        float g = dy[off + i];
+        float dxn;
+        if (gamma) {
+            const float ga = gamma[off + i];
+            const float u = xn * (1.f + ga) + beta[off + i];
+            if (act_alpha >= 0.f && u < 0.f) g *= act_alpha;
+            dgamma[off + i] = g * xn; dbeta[off + i] = g;
+            dxn = g * (1.f + ga);
+        } else {
+            if (act_alpha >= 0.f && xn < 0.f) g *= act_alpha;
+            dxn = g;
+        }
+        dxn_out[off + i] = dxn;
+        s1 += dxn; s2 += dxn * xn;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { part[((size_t)b * nchunk + blockIdx.x) * 2] = s1; part[((size_t)b * nchunk + blockIdx.x) * 2 + 1] = s2; }
+}
+// xn = (x-mu)/(sd+eps).  d xn_i / d x_j = [delta_ij - 1/N]/(sd+eps) - (x_i-mu)/(sd+eps)^2 * (x_j-mu)/(N sd)
+//  => dx_j = rs*(dxn_j - S1/N) - rs^2 * (x_j - mu)/(N sd) * sum_i dxn_i (x_i-mu)
+//          = rs*(dxn_j - S1/N) - xn_j * rs * S2 / (N * sd) * ... with S2 = sum dxn*xn, (x_i-mu) = xn_i/rs:
+//     dx_j = rs*(dxn_j - S1/N) - xn_j * S2 / (N * sd)
+__global__ void in_bwd_apply_kernel(const float* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stat,
+                                    const float* __restrict__ part, float* __restrict__ dx, long per_sample, long n, int nchunk, float eps) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = i / per_sample;
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < nchunk; ++k) { s1 += part[((size_t)b * nchunk + k) * 2]; s2 += part[((size_t)b * nchunk + k) * 2 + 1]; }
+        const float mu = stat[2 * b], rs = stat[2 * b + 1];
+        const float sd = 1.f / rs - eps;
+        const float invN = 1.f / (float)per_sample;
+        const float xn = (x[i] - mu) * rs;
+        const float t = sd > 0.f ? xn * s2 * invN / sd : 0.f;
+        dx[i] = rs * (dxn[i] - s1 * invN) - t;
+    }
+}
+
+static inline int ew_grid(long n) {
+    long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" {
+
+int mmseg_norm_workspace_floats(int C) { return NORM_MAX_BLOCKS * 2 * C; }
+
+// training-mode statistics: writes mean, invstd, scale, shift [C each]; updates moving stats when non-null
+int mmseg_bn_stats(const float* x, const float* gamma, const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                   float* mov_mean, float* mov_var, float* ws, long M, int C, float eps, float momentum, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = norm_blocks(M);
+    const long rpb = (M + nblk - 1) / nblk;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, ws, M, C, rpb, 0);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, x, gamma, beta, mean, invstd,
+                       scale, shift, mov_mean, mov_var, nblk, C, M, eps, momentum);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_bn_infer_prep(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float* scale, float* shift,
+                        int C, float eps, void* stream) {
+    hipLaunchKernelGGL(bn_infer_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mov_mean, mov_var, scale, shift, C, eps);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_bn_apply(const float* x, const float* scale, const float* shift, float* y, long M, int C, int relu, void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, n4, C / 4, relu);
+    return MMSEG_CHECK_LAUNCH();
+}
+// coef: 3*C floats of scratch
+int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean, const float* invstd,
+                 float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = norm_blocks(M);
+    const long rpb = (M + nblk - 1) / nblk;
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M);
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y, x, (const float*)coef, dx, n4, C / 4, relu);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+#define IN_CHUNKS 64
+int mmseg_in_workspace_floats(int B) { return B * IN_CHUNKS * 2; }
+// stat: [B][2] output (mean, 1/(std+eps)); y = act((x-mean)*rstd*(1+gamma)+beta)
+int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float* ws, int B,
+                             long per_sample, float eps, float act_alpha, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(in_partial_kernel, dim3(IN_CHUNKS, B), dim3(256), 0, st, x, ws, per_sample, IN_CHUNKS);
+    hipLaunchKernelGGL(in_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const float*)ws, x, stat, per_sample, IN_CHUNKS, B, eps);
+    const long n = (long)B * per_sample;
+    hipLaunchKernelGGL(in_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, (const float*)stat, gamma, beta, y, per_sample, n, act_alpha);
+    return MMSEG_CHECK_LAUNCH();
+}
+// dxn: scratch [B*per_sample]; dgamma/dbeta may be nullptr when gamma is nullptr
+int mmseg_instnorm_spade_bwd(const float* dy, const float* x, const float* stat, const float* gamma, const float* beta, float* dx,
+                             float* dgamma, float* dbeta, float* dxn, float* ws, int B, long per_sample, float eps, float act_alpha,
+                             void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(IN_CHUNKS, B), dim3(256), 0, st, dy, x, stat, gamma, beta, dgamma, dbeta, dxn, ws,
+                       per_sample, IN_CHUNKS, act_alpha);
+    const long n = (long)B * per_sample;
+    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, (const float*)dxn, x, stat, (const float*)ws, dx, per_sample, n, IN_CHUNKS, eps);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+}  // extern "C"

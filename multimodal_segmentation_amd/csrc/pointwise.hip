@@ -1,0 +1,418 @@
+// HBM-bound elementwise / small-reduction kernels of the DAFNet/MMSDNet step (gfx950).
+// All tensors NHWC fp32, contiguous.  Grid-stride loops, 16-byte accesses where the shape allows.
+// Reference ops replaced (file:line in /root/reference): keras Activation/LeakyReLU, Add, MaxPooling2D,
+// UpSampling2D grad, softmax + layers/rounding.py:23-42, layers/film.py:26-36, keras Maximum
+// (model_components/anatomy_fuser.py:33), channel slicing Lambda (models/dafnet.py:187),
+// utils/sdnet_utils.py:9-21 + costs.py:186-189.
+#include "common.hpp"
+
+static inline int grid_for(long n, int threads) {
+    long b = (n + threads - 1) / threads;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = act_apply(x[i], act, alpha);
+}
+
+// dx = dy * act'(y)   (y = activation OUTPUT)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                               long n4, long n, int act, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i], o = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = g[e] * act_grad_from_out(o[e], act, alpha);
+        reinterpret_cast<f32x4*>(dx)[i] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long i = n4 * 4; i < n; ++i) dx[i] = dy[i] * act_grad_from_out(y[i], act, alpha);
+}
+
+// out = a * sa + b * sb
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                             long n4, long n, float sa, float sb) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 u = reinterpret_cast<const f32x4*>(a)[i], v = reinterpret_cast<const f32x4*>(b)[i];
+        reinterpret_cast<f32x4*>(out)[i] = u * sa + v * sb;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long i = n4 * 4; i < n; ++i) out[i] = a[i] * sa + b[i] * sb;
+}
+
+__global__ void fill_kernel(float* __restrict__ x, long n, float v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = v;
+}
+
+// ---- column sums: out[c] = sum_m x[m][c]; two deterministic stages -------------------------------
+// stage 1: block (bx over row chunks) accumulates its rows; threads own (row lane, channel) pairs
+__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long M, int C,
+                                      long rows_per_block) {
+    // blockDim.x = 256; channel = tid % cw, row lane = tid / cw with cw = min(C, 256)
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x;
+    const int cw = min(C, 256);
+    const int rl = 256 / cw;             // row lanes (>= 1)
+    const int c_in = tid % cw, r_in = tid / cw;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int cb = 0; cb < C; cb += cw) {
+        const int c = cb + c_in;
+        float s = 0.f;
+        if (c < C && r_in < rl)
+            for (long r = r0 + r_in; r < r1; r += rl) s += x[r * C + c];
+        sm[tid] = s;
+        __syncthreads();
+        if (tid < cw && c < C) {
+            float t = 0.f;
+            for (int k = 0; k < rl; ++k) t += sm[k * cw + tid];
+            part[(size_t)blockIdx.x * C + c] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C,
+                                    float scale, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += part[(size_t)b * C + c];
+    t *= scale;
+    out[c] = accumulate ? out[c] + t : t;
+}
+
+// ---- 2x2 max pooling ------------------------------------------------------------------------------
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long n = (long)B * Ho * Wo * C4;
+    const f32x4* X = reinterpret_cast<const f32x4*>(x);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4; long r = i / C4;
+        const int wo = r % Wo; r /= Wo;
+        const int ho = r % Ho; const int b = r / Ho;
+        const long base = (((long)b * H + 2 * ho) * W + 2 * wo) * C4 + c;
+        const f32x4 v00 = X[base], v01 = X[base + C4], v10 = X[base + (long)W * C4], v11 = X[base + (long)W * C4 + C4];
+        f32x4 m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+        reinterpret_cast<f32x4*>(y)[i] = m;
+    }
+}
+
+// gradient goes to the FIRST maximum in row-major window order (TF MaxPoolGrad / torch CPU rule)
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                    float* __restrict__ dx, int B, int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long n = (long)B * Ho * Wo * C4;
+    const f32x4* X = reinterpret_cast<const f32x4*>(x);
+    f32x4* DX = reinterpret_cast<f32x4*>(dx);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4; long r = i / C4;
+        const int wo = r % Wo; r /= Wo;
+        const int ho = r % Ho; const int b = r / Ho;
+        const long base = (((long)b * H + 2 * ho) * W + 2 * wo) * C4 + c;
+        const long o01 = C4, o10 = (long)W * C4, o11 = (long)W * C4 + C4;
+        const f32x4 v00 = X[base], v01 = X[base + o01], v10 = X[base + o10], v11 = X[base + o11];
+        const f32x4 m = reinterpret_cast<const f32x4*>(y)[i], g = reinterpret_cast<const f32x4*>(dy)[i];
+        f32x4 g00, g01, g10, g11;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool a = v00[e] == m[e];
+            const bool bb = !a && v01[e] == m[e];
+            const bool cc = !a && !bb && v10[e] == m[e];
+            const bool dd = !a && !bb && !cc;
+            g00[e] = a ? g[e] : 0.f; g01[e] = bb ? g[e] : 0.f; g10[e] = cc ? g[e] : 0.f; g11[e] = dd ? g[e] : 0.f;
+        }
+        DX[base] = g00; DX[base + o01] = g01; DX[base + o10] = g10; DX[base + o11] = g11;
+    }
+    // odd trailing rows/cols (not pooled) are zeroed by the launcher when H or W is odd
+}
+
+// dx[b, h, w, c] = sum of the 2x2 block of dy (gradient of nearest x2 up-sampling)
+__global__ void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C4) {
+    // H, W: low-res dims; dy is [B, 2H, 2W, C]
+    const long n = (long)B * H * W * C4;
+    const f32x4* DY = reinterpret_cast<const f32x4*>(dy);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4; long r = i / C4;
+        const int w = r % W; r /= W;
+        const int h = r % H; const int b = r / H;
+        const long base = (((long)b * 2 * H + 2 * h) * 2 * W + 2 * w) * C4 + c;
+        reinterpret_cast<f32x4*>(dx)[i] = DY[base] + DY[base + C4] + DY[base + 2L * W * C4] + DY[base + 2L * W * C4 + C4];
+    }
+}
+
+// ---- channel softmax (+ round half-to-even) ---------------------------------------------------------
+template <int C>
+__global__ void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ p, float* __restrict__ s, long npix) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        float v[C];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { v[c] = x[i * C + c]; mx = fmaxf(mx, v[c]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float q = v[c] * inv;
+            p[i * C + c] = q;
+            if (s) s[i * C + c] = rintf(q);
+        }
+    }
+}
+
+// dx = p * (dy - sum_c dy*p)
+template <int C>
+__global__ void softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ p, float* __restrict__ dx, long npix) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        float g[C], q[C], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { g[c] = dy[i * C + c]; q[c] = p[i * C + c]; dot += g[c] * q[c]; }
+#pragma unroll
+        for (int c = 0; c < C; ++c) dx[i * C + c] = q[c] * (g[c] - dot);
+    }
+}
+
+// ---- FiLM: y = leaky(x * gamma[b,c] + beta[b,c]) (+ optional residual: y += res) ---------------------
+__global__ void film_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ res, float* __restrict__ y, int B, long HW, int C, float alpha) {
+    const long n = (long)B * HW * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C; const int b = i / (HW * C);
+        float v = x[i] * gamma[b * C + c] + beta[b * C + c];
+        v = v >= 0.f ? v : v * alpha;
+        y[i] = res ? v + res[i] : v;
+    }
+}
+
+// backward of u = leaky(x*gamma+beta): given du, x, gamma, beta ->
+//   dx = g*gamma,  part_dgamma[blk][b][c] = sum g*x,  part_dbeta = sum g   with g = du * leaky'(x*gamma+beta)
+__global__ void film_bwd_kernel(const float* __restrict__ du, const float* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ part,
+                                int B, long HW, int C, float alpha, int nchunk) {
+    // grid = (nchunk, B); block 256 threads; C must divide 256
+    extern __shared__ float sm[];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int c = tid % C, pl = tid / C, npl = blockDim.x / C;
+    const long per = (HW + nchunk - 1) / nchunk;
+    const long p0 = (long)blockIdx.x * per, p1 = min(HW, p0 + per);
+    const float ga = gamma[b * C + c], be = beta[b * C + c];
+    float sg = 0.f, sb = 0.f;
+    for (long px = p0 + pl; px < p1; px += npl) {
+        const long i = ((long)b * HW + px) * C + c;
+        const float xv = x[i];
+        const float pre = xv * ga + be;
+        const float g = du[i] * (pre >= 0.f ? 1.f : alpha);
+        dx[i] = g * ga;
+        sg += g * xv; sb += g;
+    }
+    sm[tid] = sg; sm[blockDim.x + tid] = sb;
+    __syncthreads();
+    if (tid < C) {
+        float tg = 0.f, tb = 0.f;
+        for (int k = 0; k < npl; ++k) { tg += sm[k * C + tid]; tb += sm[blockDim.x + k * C + tid]; }
+        float* o = part + ((size_t)blockIdx.x * B + b) * 2 * C;
+        o[tid] = tg; o[C + tid] = tb;
+    }
+}
+
+__global__ void film_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                      int B, int C, int nchunk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    float tg = 0.f, tb = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        const float* o = part + ((size_t)k * B + b) * 2 * C;
+        tg += o[c]; tb += o[C + c];
+    }
+    dgamma[i] = tg; dbeta[i] = tb;
+}
+
+// ---- element-wise maximum (tf.maximum gradient rule: ties go to the FIRST argument) -----------------------
+__global__ void maximum_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = fmaxf(a[i], b[i]);
+}
+__global__ void maximum_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dy,
+                                   float* __restrict__ da, float* __restrict__ db, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const bool first = a[i] >= b[i];
+        const float g = dy[i];
+        if (da) da[i] = first ? g : 0.f;
+        if (db) db[i] = first ? 0.f : g;
+    }
+}
+
+// ---- channel slice copy: y[m, 0:Cs] = x[m, c0:c0+Cs]; backward scatters into a zeroed tensor ---------------
+__global__ void slice_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long M, int C, int c0, int Cs) {
+    const long n = M * Cs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / Cs; const int c = i % Cs;
+        y[i] = x[m * C + c0 + c];
+    }
+}
+__global__ void slice_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long M, int C, int c0, int Cs) {
+    const long n = M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / C; const int c = i % C;
+        dx[i] = (c >= c0 && c < c0 + Cs) ? dy[m * Cs + (c - c0)] : 0.f;
+    }
+}
+
+// ---- VAE sampling + KL (tiny: B x Z) ------------------------------------------------------------------------
+__global__ void sampling_kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
+                                       float* __restrict__ z, float* __restrict__ kl, int B, int Z) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float acc = 0.f;
+    for (int j = 0; j < Z; ++j) {
+        const float m = mu[b * Z + j], l = lv[b * Z + j];
+        z[b * Z + j] = m + expf(0.5f * l) * eps[b * Z + j];
+        acc += 1.f + l - m * m - expf(l);
+    }
+    kl[b] = -0.5f * acc;
+}
+// dmu = dz + dkl*mu ; dlv = dz*0.5*exp(0.5 lv)*eps + dkl*(-0.5)(1 - exp(lv))
+__global__ void sampling_kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
+                                       const float* __restrict__ dz, const float* __restrict__ dkl, float* __restrict__ dmu,
+                                       float* __restrict__ dlv, int B, int Z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Z) return;
+    const int b = i / Z;
+    const float m = mu[i], l = lv[i];
+    const float gz = dz ? dz[i] : 0.f, gk = dkl ? dkl[b] : 0.f;
+    dmu[i] = gz + gk * m;
+    dlv[i] = gz * 0.5f * expf(0.5f * l) * eps[i] + gk * (-0.5f) * (1.f - expf(l));
+}
+
+extern "C" {
+
+int mmseg_act_fwd(const float* x, float* y, long n, int act, float alpha, void* stream) {
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, act, alpha);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float alpha, void* stream) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n / 4, n, act, alpha);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_axpby(const float* a, const float* b, float* out, long n, float sa, float sb, void* stream) {
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, n, sa, sb);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_fill(float* x, long n, float v, void* stream) {
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, v);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+// workspace: nblk * C floats, nblk = mmseg_colsum_blocks(M)
+int mmseg_colsum_blocks(long M) {
+    long nb = (M + 1023) / 1024;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+int mmseg_colsum(const float* x, float* out, float* ws, long M, int C, float scale, int accumulate, void* stream) {
+    const int nblk = mmseg_colsum_blocks(M);
+    const long rpb = (M + nblk - 1) / nblk;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), st, x, ws, M, C, rpb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, out, nblk, C, scale, accumulate);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    if ((C & 3) || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+    const long n = (long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+    if ((C & 3) || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+    const long n = (long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, dx, B, H, W, C / 4);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_upsample2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    const long n = (long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C / 4);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_softmax_fwd(const float* x, float* p, float* s, long npix, int C, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g(grid_for(npix, 256)), b(256);
+    switch (C) {
+        case 3: hipLaunchKernelGGL(softmax_fwd_kernel<3>, g, b, 0, st, x, p, s, npix); break;
+        case 5: hipLaunchKernelGGL(softmax_fwd_kernel<5>, g, b, 0, st, x, p, s, npix); break;
+        case 8: hipLaunchKernelGGL(softmax_fwd_kernel<8>, g, b, 0, st, x, p, s, npix); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_softmax_bwd(const float* dy, const float* p, float* dx, long npix, int C, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g(grid_for(npix, 256)), b(256);
+    switch (C) {
+        case 3: hipLaunchKernelGGL(softmax_bwd_kernel<3>, g, b, 0, st, dy, p, dx, npix); break;
+        case 5: hipLaunchKernelGGL(softmax_bwd_kernel<5>, g, b, 0, st, dy, p, dx, npix); break;
+        case 8: hipLaunchKernelGGL(softmax_bwd_kernel<8>, g, b, 0, st, dy, p, dx, npix); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_film_fwd(const float* x, const float* gamma, const float* beta, const float* res, float* y, int B, long HW, int C,
+                   float alpha, void* stream) {
+    const long n = (long)B * HW * C;
+    hipLaunchKernelGGL(film_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, res, y, B, HW, C, alpha);
+    return MMSEG_CHECK_LAUNCH();
+}
+#define FILM_CHUNKS 128
+int mmseg_film_bwd_workspace(int B, int C) { return FILM_CHUNKS * B * 2 * C; }
+int mmseg_film_bwd(const float* du, const float* x, const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                   float* ws, int B, long HW, int C, float alpha, void* stream) {
+    if (C > 256 || 256 % C != 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(film_bwd_kernel, dim3(FILM_CHUNKS, B), dim3(256), 2 * 256 * sizeof(float), st, du, x, gamma, beta, dx, ws, B, HW, C, alpha, FILM_CHUNKS);
+    hipLaunchKernelGGL(film_bwd_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, (const float*)ws, dgamma, dbeta, B, C, FILM_CHUNKS);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_maximum_fwd(const float* a, const float* b, float* y, long n, void* stream) {
+    hipLaunchKernelGGL(maximum_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_maximum_bwd(const float* a, const float* b, const float* dy, float* da, float* db, long n, void* stream) {
+    hipLaunchKernelGGL(maximum_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, dy, da, db, n);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_slice_fwd(const float* x, float* y, long M, int C, int c0, int Cs, void* stream) {
+    if (c0 < 0 || c0 + Cs > C) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(slice_fwd_kernel, dim3(grid_for(M * Cs, 256)), dim3(256), 0, (hipStream_t)stream, x, y, M, C, c0, Cs);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_slice_bwd(const float* dy, float* dx, long M, int C, int c0, int Cs, void* stream) {
+    if (c0 < 0 || c0 + Cs > C) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(slice_bwd_kernel, dim3(grid_for(M * C, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, M, C, c0, Cs);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_sampling_kl_fwd(const float* mu, const float* lv, const float* eps, float* z, float* kl, int B, int Z, void* stream) {
+    hipLaunchKernelGGL(sampling_kl_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, mu, lv, eps, z, kl, B, Z);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_sampling_kl_bwd(const float* mu, const float* lv, const float* eps, const float* dz, const float* dkl, float* dmu,
+                          float* dlv, int B, int Z, void* stream) {
+    hipLaunchKernelGGL(sampling_kl_bwd_kernel, dim3((B * Z + 63) / 64), dim3(64), 0, (hipStream_t)stream, mu, lv, eps, dz, dkl, dmu, dlv, B, Z);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// Thin-plate-spline warp of the anatomy factor (layers/stn_spline.py:36-67 + layers/interpolate_spline.py
+// + tf.contrib.resampler of the reference) for gfx950.
+//
+// Because the STN is built with inverse=False (model_components/anatomy_fuser.py:30) the spline is fitted on
+// the FIXED 5x5 control grid, so the sample locations are an affine function of the predicted offsets:
+//     loc_normalised[b, p, :] = grid[p, :] + sum_j Mb[p, j] * theta[b, j, :]
+// with a constant Mb [H*W, 25] computed once on the host in fp64 (see layers/stn_spline.py of this package).
+// The 28x28 solve per sample of the reference therefore disappears; the kernels below are a 25-term dot
+// product + a 4-tap gather per pixel (HBM/latency bound).  Coordinates follow the reference: normalised
+// (row, col) -> reversed -> scaled by (W-1, H-1) -> (x, y) in pixels; taps outside the image contribute 0.
+#include "common.hpp"
+
+#define TPS_NCP 25
+
+__device__ __forceinline__ void tps_loc(const float* __restrict__ Mb, const float* th /* LDS [25][2] */, int p, int H, int W,
+                                        float& x, float& y) {
+    const int row = p / W, col = p - row * W;
+    float lr = (float)row / (float)(H - 1), lc = (float)col / (float)(W - 1);
+    const float* m = Mb + (size_t)p * TPS_NCP;
+    float ar = 0.f, ac = 0.f;
+#pragma unroll
+    for (int j = 0; j < TPS_NCP; ++j) { const float mv = m[j]; ar += mv * th[2 * j]; ac += mv * th[2 * j + 1]; }
+    lr += ar; lc += ac;
+    x = lc * (float)(W - 1);
+    y = lr * (float)(H - 1);
+}
+
+// grid (ceil(HW/256), B)
+template <int C>
+__global__ void tps_warp_fwd_kernel(const float* __restrict__ vol, const float* __restrict__ theta, const float* __restrict__ Mb,
+                                    float* __restrict__ out, float* __restrict__ loc, int H, int W) {
+    __shared__ float th[2 * TPS_NCP];
+    const int b = blockIdx.y;
+    if (threadIdx.x < 2 * TPS_NCP) th[threadIdx.x] = theta[(size_t)b * 2 * TPS_NCP + threadIdx.x];
+    __syncthreads();
+    const int HW = H * W;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float x, y;
+    tps_loc(Mb, th, p, H, W, x, y);
+    if (loc) { loc[((size_t)b * HW + p) * 2] = x; loc[((size_t)b * HW + p) * 2 + 1] = y; }
+    const float fxf = floorf(x), fyf = floorf(y);
+    const float ax = x - fxf, ay = y - fyf;
+    // clamp before the int conversion so that wild offsets cannot overflow
+    const int fx = (int)fminf(fmaxf(fxf, -2.f), (float)W), fy = (int)fminf(fmaxf(fyf, -2.f), (float)H);
+    const float* vb = vol + (size_t)b * HW * C;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int xi = fx + (t & 1), yi = fy + (t >> 1);
+        const float wgt = ((t & 1) ? ax : 1.f - ax) * ((t >> 1) ? ay : 1.f - ay);
+        if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
+            const float* src = vb + ((size_t)yi * W + xi) * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] += wgt * src[c];
+        }
+    }
+    float* o = out + ((size_t)b * HW + p) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = acc[c];
+}
+
+// backward: d_vol via float atomics (scatter), d_loc[b,p,2] = (dL/dx, dL/dy) in pixel units
+template <int C>
+__global__ void tps_warp_bwd_kernel(const float* __restrict__ vol, const float* __restrict__ loc, const float* __restrict__ dout,
+                                    float* __restrict__ dvol, float* __restrict__ dloc, int H, int W) {
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float x = loc[((size_t)b * HW + p) * 2], y = loc[((size_t)b * HW + p) * 2 + 1];
+    const float fxf = floorf(x), fyf = floorf(y);
+    const float ax = x - fxf, ay = y - fyf;
+    const int fx = (int)fminf(fmaxf(fxf, -2.f), (float)W), fy = (int)fminf(fmaxf(fyf, -2.f), (float)H);
+    const float* vb = vol + (size_t)b * HW * C;
+    float* dvb = dvol ? dvol + (size_t)b * HW * C : nullptr;
+    float g[C];
+    const float* go = dout + ((size_t)b * HW + p) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = go[c];
+    float gx = 0.f, gy = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int xi = fx + (t & 1), yi = fy + (t >> 1);
+        if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
+            const float wx = (t & 1) ? ax : 1.f - ax, wy = (t >> 1) ? ay : 1.f - ay;
+            const float sx = (t & 1) ? 1.f : -1.f, sy = (t >> 1) ? 1.f : -1.f;
+            const float* src = vb + ((size_t)yi * W + xi) * C;
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                dot += g[c] * src[c];
+                if (dvb) atomicAdd(dvb + ((size_t)yi * W + xi) * C + c, g[c] * wx * wy);
+            }
+            gx += dot * sx * wy;
+            gy += dot * sy * wx;
+        }
+    }
+    if (dloc) { dloc[((size_t)b * HW + p) * 2] = gx; dloc[((size_t)b * HW + p) * 2 + 1] = gy; }
+}
+
+// part[chunk][b][j][2]: dtheta[b][j][0] (row offset) = sum_p Mb[p][j] * dloc_y * (H-1); [1] (col) uses dloc_x * (W-1)
+__global__ void tps_dtheta_partial_kernel(const float* __restrict__ dloc, const float* __restrict__ Mb, float* __restrict__ part,
+                                          int B, int H, int W, int per) {
+    const int HW = H * W;
+    const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+    const int ncombo = B * TPS_NCP * 2;
+    for (int q = threadIdx.x; q < ncombo; q += blockDim.x) {
+        const int k = q & 1, j = (q >> 1) % TPS_NCP, b = (q >> 1) / TPS_NCP;
+        const float sc = k == 0 ? (float)(H - 1) : (float)(W - 1);
+        const float* dl = dloc + (size_t)b * HW * 2 + (k == 0 ? 1 : 0);
+        float a = 0.f;
+        for (int p = p0; p < p1; ++p) a += Mb[(size_t)p * TPS_NCP + j] * dl[(size_t)p * 2];
+        part[(size_t)blockIdx.x * ncombo + q] = a * sc;
+    }
+}
+__global__ void tps_dtheta_final_kernel(const float* __restrict__ part, float* __restrict__ dtheta, int ncombo, int nchunk) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ncombo) return;
+    float a = 0.f;
+    for (int s = 0; s < nchunk; ++s) a += part[(size_t)s * ncombo + q];
+    dtheta[q] = a;
+}
+
+#define TPS_CHUNKS 256
+
+extern "C" {
+
+int mmseg_tps_workspace_floats(int B) { return TPS_CHUNKS * B * TPS_NCP * 2; }
+
+int mmseg_tps_warp_fwd(const float* vol, const float* theta, const float* Mb, float* out, float* loc, int B, int H, int W, int C,
+                       void* stream) {
+    if (C != 8 || H < 2 || W < 2) return (int)hipErrorInvalidValue;
+    dim3 grid((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(tps_warp_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, vol, theta, Mb, out, loc, H, W);
+    return MMSEG_CHECK_LAUNCH();
+}
+// dvol must be zero-filled by the caller (scatter-add); dvol or dtheta may be nullptr to skip that gradient
+int mmseg_tps_warp_bwd(const float* vol, const float* loc, const float* Mb, const float* dout, float* dvol, float* dtheta, float* dloc,
+                       float* ws, int B, int H, int W, int C, void* stream) {
+    if (C != 8) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(tps_warp_bwd_kernel<8>, grid, dim3(256), 0, st, vol, loc, dout, dvol, dtheta ? dloc : (float*)nullptr, H, W);
+    if (dtheta) {
+        const int per = (H * W + TPS_CHUNKS - 1) / TPS_CHUNKS;
+        const int ncombo = B * TPS_NCP * 2;
+        hipLaunchKernelGGL(tps_dtheta_partial_kernel, dim3(TPS_CHUNKS), dim3(256), 0, st, (const float*)dloc, Mb, ws, B, H, W, per);
+        hipLaunchKernelGGL(tps_dtheta_final_kernel, dim3((ncombo + 255) / 256), dim3(256), 0, st, (const float*)ws, dtheta, ncombo, TPS_CHUNKS);
+    }
+    return MMSEG_CHECK_LAUNCH();
+}
+
+}  // extern "C"

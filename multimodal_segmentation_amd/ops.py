@@ -1,0 +1,573 @@
+"""Operators of the DAFNet/MMSDNet step: thin autograd nodes around the gfx950 kernels of libmmseg_hip.so.
+
+torch is used for device memory (torch.empty), the stream and the autograd tape that stitches the nodes; every
+arithmetic operation on activations, gradients and weights is a kernel of csrc/*.hip reached through
+_native.call (C ABI, include/mmseg_hip.h).  Layout: NHWC fp32 (the reference's layout), weights in Keras
+layout (conv HWIO, dense [in, out]).
+"""
+import torch
+
+from . import _native as N
+
+ACT = {None: 0, 'linear': 0, 'relu': 1, 'leaky': 2, 'tanh': 3}
+BN_EPS = 1e-3        # keras BatchNormalization default
+BN_MOMENTUM = 0.99   # keras BatchNormalization default
+IN_EPS = 1e-3        # keras_contrib InstanceNormalization default
+
+_workspaces = {}
+
+
+def _ws(tag, nfloats, device):
+    """Grow-only scratch buffer per (tag, device).  All kernels of one process run in stream order on the compute
+    stream, so a buffer can be handed to the next kernel as soon as the previous launch has been queued."""
+    key = (tag, device)
+    buf = _workspaces.get(key)
+    n = max(int(nfloats), 1)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1024), dtype=torch.float32, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _new(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------------
+def _conv_geometry(H, W, KH, KW, stride, padding):
+    if padding == 'same':
+        if stride != 1 or KH % 2 == 0 or KW % 2 == 0:
+            raise ValueError("'same' is implemented for stride 1 and odd kernels (all the reference uses)")
+        return H, W, KH // 2, KW // 2
+    if padding == 'valid':
+        return (H - KH) // stride + 1, (W - KW) // stride + 1, 0, 0
+    raise ValueError(padding)
+
+
+def _conv_fwd_raw(x1, x2, w, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, transposed,
+                  act, alpha, nsplit1):
+    # host-side shape checks: the kernel trusts these numbers
+    assert x1.numel() == B * (H >> ups) * (W >> ups) * C1, 'x1 shape/geometry mismatch'
+    assert (x2 is None and C2 == 0) or x2.numel() == B * H * W * C2, 'x2 shape/geometry mismatch'
+    assert w.numel() == KH * KW * (C1 + C2) * Cout, 'kernel shape mismatch'
+    assert bias is None or bias.numel() == Cout
+    if y2 is None:
+        assert y.numel() == B * Ho * Wo * Cout
+    else:
+        assert y.numel() == B * Ho * Wo * nsplit1 and y2.numel() == B * Ho * Wo * (Cout - nsplit1)
+    N.call('mmseg_conv2d_fwd', x1, x2, w, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw,
+           ups, transposed, act, float(alpha), nsplit1)
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, w, bias, stride, padding, act, alpha, ups):
+        x1 = _c(x1)
+        x2 = _c(x2) if x2 is not None else None
+        B, H1, W1, C1 = x1.shape
+        H, W = (H1 * 2, W1 * 2) if ups else (H1, W1)
+        C2 = 0 if x2 is None else x2.shape[3]
+        if x2 is not None:
+            assert x2.shape[:3] == (B, H, W)
+        KH, KW, Cin, Cout = w.shape
+        assert Cin == C1 + C2, 'kernel expects %d input channels, got %d' % (Cin, C1 + C2)
+        Ho, Wo, ph, pw = _conv_geometry(H, W, KH, KW, stride, padding)
+        y = _new((B, Ho, Wo, Cout), x1)
+        _conv_fwd_raw(x1, x2, w, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,
+                      ACT[act], alpha, 0)
+        ctx.geom = (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), ACT[act], alpha)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x1, x2, w, y if ACT[act] else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, w, y = ctx.saved_tensors
+        B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, act, alpha = ctx.geom
+        dy = _c(dy)
+        if act:
+            g = _new(dy.shape, dy)
+            N.call('mmseg_act_bwd', dy, y, g, dy.numel(), act, float(alpha))
+        else:
+            g = dy
+        need_x1, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
+        dx1 = dx2 = dw = db = None
+        M = B * Ho * Wo
+        if ctx.has_bias and need_b:
+            db = _new((Cout,), dy)
+            ws = _ws('colsum', N.call('mmseg_colsum_blocks', M) * Cout, dy.device)
+            N.call('mmseg_colsum', g, db, ws, M, Cout, 1.0, 0)
+        if need_w:
+            dw = _new(w.shape, dy)
+            need = N.call('mmseg_conv2d_wgrad_workspace', B, Ho, Wo, C1 + C2, Cout, KH, KW)
+            ws = _ws('wgrad', need, dy.device)
+            N.call('mmseg_conv2d_wgrad', x1, x2, g, dw, ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride,
+                   ph, pw, ups)
+        if need_x1 or (x2 is not None and need_x2):
+            Cin = C1 + C2
+            wt = _ws('wflip', w.numel(), dy.device)[:w.numel()]
+            N.call('mmseg_conv2d_wflip', w, wt, KH, KW, Cin, Cout)
+            d1 = _new((B, H, W, C1), dy)
+            d2 = _new((B, H, W, C2), dy) if C2 else None
+            # data gradient = convolution of g with the flipped kernel; fractionally strided when stride > 1
+            _conv_fwd_raw(g, None, wt, None, d1, d2, B, Ho, Wo, Cout, 0, H, W, Cin, KH, KW, stride, KH - 1 - ph,
+                          KW - 1 - pw, 0, 1 if stride > 1 else 0, 0, 0.0, C1 if C2 else 0)
+            if ups:
+                dx1 = _new((B, H // 2, W // 2, C1), dy)
+                N.call('mmseg_upsample2_bwd', d1, dx1, B, H // 2, W // 2, C1)
+            else:
+                dx1 = d1
+            dx2 = d2
+        return dx1, dx2, dw, db, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False):
+    """keras Conv2D on NHWC (+ fused nearest x2 up-sampling of x, + fused channel concat with x2, + fused
+    bias/activation epilogue)."""
+    if upsample and (x.shape[3] % 4 != 0):
+        raise ValueError('fused up-sampling needs C % 4 == 0')
+    return _Conv2d.apply(x, x2, w, bias, stride, padding, act, alpha, bool(upsample))
+
+
+# ------------------------------------------------------------------------------------------------------
+# batch norm (+ReLU)
+# ------------------------------------------------------------------------------------------------------
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mov_mean, mov_var, relu):
+        x = _c(x)
+        C = x.shape[-1]
+        M = x.numel() // C
+        stats = _new((4, C), x)  # mean, invstd, scale, shift
+        ws = _ws('norm', N.call('mmseg_norm_workspace_floats', C), x.device)
+        N.call('mmseg_bn_stats', x, gamma, beta, stats[0], stats[1], stats[2], stats[3], mov_mean, mov_var, ws, M, C,
+               BN_EPS, BN_MOMENTUM)
+        y = _new(x.shape, x)
+        N.call('mmseg_bn_apply', x, stats[2], stats[3], y, M, C, int(relu))
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, y if relu else None, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, stats = ctx.saved_tensors
+        dy = _c(dy)
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = _new(x.shape, x)
+        dgamma, dbeta = _new((C,), x), _new((C,), x)
+        coef = _ws('bn_coef', 3 * C, x.device)
+        ws = _ws('norm', N.call('mmseg_norm_workspace_floats', C), x.device)
+        N.call('mmseg_bn_bwd', dy, y, x, gamma, stats[0], stats[1], dx, dgamma, dbeta, coef, ws, M, C, int(ctx.relu))
+        return dx, dgamma, dbeta, None, None, None
+
+
+def batchnorm(x, gamma, beta, mov_mean, mov_var, training, relu=False):
+    """keras BatchNormalization(axis=-1) [+ ReLU].  training: batch statistics and in-place moving-average update
+    (what `fit` does); otherwise the moving statistics (what `predict` does)."""
+    if training:
+        return _BatchNormTrain.apply(x, gamma, beta, mov_mean, mov_var, relu)
+    x = _c(x)
+    C = x.shape[-1]
+    M = x.numel() // C
+    ss = _new((2, C), x)
+    N.call('mmseg_bn_infer_prep', gamma, beta, mov_mean, mov_var, ss[0], ss[1], C, BN_EPS)
+    y = _new(x.shape, x)
+    N.call('mmseg_bn_apply', x, ss[0], ss[1], y, M, C, int(relu))
+    return y
+
+
+# ------------------------------------------------------------------------------------------------------
+# pooling / softmax / rounding
+# ------------------------------------------------------------------------------------------------------
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, H, W, C = x.shape
+        y = _new((B, H // 2, W // 2, C), x)
+        N.call('mmseg_maxpool2_fwd', x, y, B, H, W, C)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dx = _new(x.shape, x)
+        N.call('mmseg_maxpool2_bwd', x, y, _c(dy), dx, B, H, W, C)
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _SoftmaxRound(torch.autograd.Function):
+    """-> (p, s): channel softmax and its half-to-even rounding with the straight-through gradient of
+    layers/rounding.py:40-42 (the gradient reaching s is passed to p unchanged)."""
+
+    @staticmethod
+    def forward(ctx, x, want_round):
+        x = _c(x)
+        C = x.shape[-1]
+        p = _new(x.shape, x)
+        s = _new(x.shape, x) if want_round else None
+        N.call('mmseg_softmax_fwd', x, p, s, x.numel() // C, C)
+        ctx.save_for_backward(p)
+        return p, s
+
+    @staticmethod
+    def backward(ctx, dp, ds):
+        (p,) = ctx.saved_tensors
+        C = p.shape[-1]
+        if dp is None:
+            g = _c(ds)
+        elif ds is None:
+            g = _c(dp)
+        else:
+            g = _new(p.shape, p)
+            N.call('mmseg_axpby', _c(dp), _c(ds), g, p.numel(), 1.0, 1.0)
+        dx = _new(p.shape, p)
+        N.call('mmseg_softmax_bwd', g, p, dx, p.numel() // C, C)
+        return dx, None
+
+
+def softmax(x):
+    return _SoftmaxRound.apply(x, False)[0]
+
+
+def softmax_round(x):
+    """-> (softmax, rounded softmax)"""
+    return _SoftmaxRound.apply(x, True)
+
+
+# ------------------------------------------------------------------------------------------------------
+# dense
+# ------------------------------------------------------------------------------------------------------
+class _Dense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, act, alpha):
+        x = _c(x)
+        R, K = x.shape
+        K2, Nn = w.shape
+        assert K == K2, 'dense: input has %d features, kernel expects %d' % (K, K2)
+        y = _new((R, Nn), x)
+        ws = _ws('dense', N.call('mmseg_dense_workspace_floats', R, K, Nn), x.device)
+        N.call('mmseg_dense_fwd', x, w, bias, y, ws, R, K, Nn, ACT[act], float(alpha))
+        ctx.act, ctx.alpha, ctx.has_bias = ACT[act], alpha, bias is not None
+        ctx.save_for_backward(x, w, y if ACT[act] else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        R, K = x.shape
+        Nn = w.shape[1]
+        dy = _c(dy)
+        if ctx.act:
+            g = _new(dy.shape, dy)
+            N.call('mmseg_act_bwd', dy, y, g, dy.numel(), ctx.act, float(ctx.alpha))
+        else:
+            g = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _new(x.shape, x)
+            N.call('mmseg_dense_dgrad', g, w, dx, R, K, Nn)
+        if ctx.needs_input_grad[1]:
+            dw = _new(w.shape, x)
+            N.call('mmseg_dense_wgrad', x, g, dw, R, K, Nn)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _new((Nn,), x)
+            ws = _ws('colsum', N.call('mmseg_colsum_blocks', R) * Nn, x.device)
+            N.call('mmseg_colsum', g, db, ws, R, Nn, 1.0, 0)
+        return dx, dw, db, None, None
+
+
+def dense(x, w, bias=None, act=None, alpha=0.0):
+    return _Dense.apply(x, w, bias, act, alpha)
+
+
+# ------------------------------------------------------------------------------------------------------
+# FiLM (+LeakyReLU + residual add)
+# ------------------------------------------------------------------------------------------------------
+class _Film(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, alpha):
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        B, H, W, C = x.shape
+        assert gamma.shape == (B, C) and beta.shape == (B, C)
+        y = _new(x.shape, x)
+        N.call('mmseg_film_fwd', x, gamma, beta, _c(res) if res is not None else None, y, B, H * W, C, float(alpha))
+        ctx.alpha, ctx.has_res = alpha, res is not None
+        ctx.save_for_backward(x, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dy = _c(dy)
+        dx = _new(x.shape, x)
+        dg, db = _new((B, C), x), _new((B, C), x)
+        ws = _ws('film', N.call('mmseg_film_bwd_workspace', B, C), x.device)
+        N.call('mmseg_film_bwd', dy, x, gamma, beta, dx, dg, db, ws, B, H * W, C, float(ctx.alpha))
+        return dx, dg, db, (dy if ctx.has_res else None), None
+
+
+def film(x, gamma, beta, res=None, alpha=0.3):
+    """leaky_relu(x * gamma + beta, alpha) [+ res]  (layers/film.py:26-36 + decoder.py:50-53)."""
+    return _Film.apply(x, gamma, beta, res, alpha)
+
+
+# ------------------------------------------------------------------------------------------------------
+# thin-plate-spline warp, maximum, slice, sampling
+# ------------------------------------------------------------------------------------------------------
+class _TpsWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol, theta, Mb):
+        vol, theta = _c(vol), _c(theta)
+        B, H, W, C = vol.shape
+        assert theta.numel() == B * 50 and Mb.shape == (H * W, 25)
+        out = _new(vol.shape, vol)
+        loc = _new((B, H * W, 2), vol)
+        N.call('mmseg_tps_warp_fwd', vol, theta, Mb, out, loc, B, H, W, C)
+        ctx.save_for_backward(vol, loc, Mb)
+        ctx.theta_shape = theta.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        vol, loc, Mb = ctx.saved_tensors
+        B, H, W, C = vol.shape
+        dout = _c(dout)
+        dvol = dtheta = None
+        if ctx.needs_input_grad[0]:
+            dvol = _new(vol.shape, vol)
+            N.call('mmseg_fill', dvol, dvol.numel(), 0.0)
+        dloc = None
+        ws = None
+        if ctx.needs_input_grad[1]:
+            dtheta = _new(ctx.theta_shape, vol)
+            dloc = _ws('tps_dloc', B * H * W * 2, vol.device)
+            ws = _ws('tps', N.call('mmseg_tps_workspace_floats', B), vol.device)
+        N.call('mmseg_tps_warp_bwd', vol, loc, Mb, dout, dvol, dtheta, dloc, ws, B, H, W, C)
+        return dvol, dtheta, None
+
+
+def tps_warp(vol, theta, Mb):
+    return _TpsWarp.apply(vol, theta, Mb)
+
+
+class _Maximum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        y = _new(a.shape, a)
+        N.call('mmseg_maximum_fwd', a, b, y, a.numel())
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        da = _new(a.shape, a) if ctx.needs_input_grad[0] else None
+        db = _new(a.shape, a) if ctx.needs_input_grad[1] else None
+        N.call('mmseg_maximum_bwd', a, b, _c(dy), da, db, a.numel())
+        return da, db
+
+
+def maximum(a, b):
+    return _Maximum.apply(a, b)
+
+
+class _SliceChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c0, cs):
+        x = _c(x)
+        C = x.shape[-1]
+        y = _new(x.shape[:-1] + (cs,), x)
+        N.call('mmseg_slice_fwd', x, y, x.numel() // C, C, c0, cs)
+        ctx.meta = (x.shape, c0, cs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, c0, cs = ctx.meta
+        dx = _new(shape, dy)
+        N.call('mmseg_slice_bwd', _c(dy), dx, dx.numel() // shape[-1], shape[-1], c0, cs)
+        return dx, None, None
+
+
+def slice_channels(x, c0, cs):
+    return _SliceChannels.apply(x, c0, cs)
+
+
+class _SamplingKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, lv, eps):
+        mu, lv, eps = _c(mu), _c(lv), _c(eps)
+        B, Z = mu.shape
+        z, kl = _new((B, Z), mu), _new((B, 1), mu)
+        N.call('mmseg_sampling_kl_fwd', mu, lv, eps, z, kl, B, Z)
+        ctx.save_for_backward(mu, lv, eps)
+        return z, kl
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        mu, lv, eps = ctx.saved_tensors
+        B, Z = mu.shape
+        dmu, dlv = _new((B, Z), mu), _new((B, Z), mu)
+        N.call('mmseg_sampling_kl_bwd', mu, lv, eps, _c(dz) if dz is not None else None,
+               _c(dkl) if dkl is not None else None, dmu, dlv, B, Z)
+        return dmu, dlv, None
+
+
+def sampling_kl(z_mean, z_log_var, eps):
+    """-> (z, kl[B,1])  (utils/sdnet_utils.py:9-21 with explicit eps, costs.py:186-189)."""
+    return _SamplingKL.apply(z_mean, z_log_var, eps)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        y = _new(a.shape, a)
+        N.call('mmseg_axpby', a, b, y, a.numel(), 1.0, 1.0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------
+# instance norm + SPADE modulation + LeakyReLU
+# ------------------------------------------------------------------------------------------------------
+class _InstNormSpade(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, act_alpha):
+        x = _c(x)
+        B = x.shape[0]
+        per = x.numel() // B
+        gamma = _c(gamma) if gamma is not None else None
+        beta = _c(beta) if beta is not None else None
+        y = _new(x.shape, x)
+        stat = _new((B, 2), x)
+        ws = _ws('instnorm', N.call('mmseg_in_workspace_floats', B), x.device)
+        N.call('mmseg_instnorm_spade_fwd', x, gamma, beta, y, stat, ws, B, per, IN_EPS, float(act_alpha))
+        ctx.act_alpha = act_alpha
+        ctx.save_for_backward(x, stat, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stat, gamma, beta = ctx.saved_tensors
+        B = x.shape[0]
+        per = x.numel() // B
+        dx = _new(x.shape, x)
+        dg = _new(x.shape, x) if gamma is not None else None
+        db = _new(x.shape, x) if gamma is not None else None
+        dxn = _ws('instnorm_dxn', x.numel(), x.device)
+        ws = _ws('instnorm', N.call('mmseg_in_workspace_floats', B), x.device)
+        N.call('mmseg_instnorm_spade_bwd', _c(dy), x, stat, gamma, beta, dx, dg, db, dxn, ws, B, per, IN_EPS,
+               float(ctx.act_alpha))
+        return dx, dg, db, None
+
+
+def instnorm_spade(x, gamma=None, beta=None, act_alpha=-1.0):
+    """act( IN(x) * (1 + gamma) + beta ); act_alpha < 0: no activation (layers/spade.py:7-33,51-54)."""
+    return _InstNormSpade.apply(x, gamma, beta, act_alpha)
+
+
+# ------------------------------------------------------------------------------------------------------
+# losses: value (device scalar) + gradient w.r.t. the prediction, no autograd node
+# ------------------------------------------------------------------------------------------------------
+def seg_loss(pred, target, num_masks, lambda_bce, scale, class_sum_hook=None, n_pix_global=None, want_grad=True):
+    """make_combined_dice_bce (lambda_bce = 0.01) or make_dice_loss_fnc (lambda_bce = 0) of costs.py.
+    `class_sum_hook(t)` may all-reduce the batch-global class sums in place (data-parallel training).
+    -> (loss[1], dpred or None); dpred already multiplied by `scale` (loss weight)."""
+    pred, target = _c(pred), _c(target)
+    B, H, W, C = pred.shape
+    dev = pred.device
+    stats = _new((N.call('mmseg_segloss_stats_floats', B),), pred)
+    ws = _ws('segloss', N.call('mmseg_segloss_workspace_floats', B), dev)
+    N.call('mmseg_segloss_stats', pred, target, stats, ws, B, H * W, C, num_masks)
+    if class_sum_hook is not None and lambda_bce != 0.0:
+        class_sum_hook(stats[N.call('mmseg_segloss_class_offset', B):])
+    loss = _new((1,), pred)
+    coef = _new((N.call('mmseg_segloss_coef_floats', B, C),), pred)
+    npg = float(B * H * W if n_pix_global is None else n_pix_global)
+    N.call('mmseg_segloss_finalize', stats, loss, coef, B, C, npg, float(lambda_bce))
+    dpred = None
+    if want_grad:
+        dpred = _new(pred.shape, pred)
+        N.call('mmseg_segloss_grad', pred, target, coef, dpred, B, H * W, C, num_masks, float(scale),
+               int(lambda_bce != 0.0))
+    return loss, dpred
+
+
+_DIFF_MODE = {'mae': 0, 'mse': 1, 'mean': 2}
+
+
+def diff_loss(pred, target, mode, scale, want_grad=True):
+    """keras 'mae' / 'mse' (target tensor or python float) or mean(pred) (costs.ypred).
+    -> (loss[1], dpred or None), dpred = scale * dloss/dpred."""
+    pred = _c(pred)
+    n = pred.numel()
+    t, tc = (None, float(target)) if not isinstance(target, torch.Tensor) else (_c(target), 0.0)
+    if t is not None:
+        assert t.numel() == n
+    loss = _new((1,), pred)
+    ws = _ws('diffloss', N.call('mmseg_diffloss_workspace_floats'), pred.device)
+    N.call('mmseg_diffloss', pred, t, tc, n, _DIFF_MODE[mode], loss, ws)
+    dpred = None
+    if want_grad:
+        dpred = _new(pred.shape, pred)
+        g = {0: 1.0 / n, 1: 1.0 / n, 2: 1.0 / n}[_DIFF_MODE[mode]] * scale
+        N.call('mmseg_diffloss_grad', pred, t, tc, n, _DIFF_MODE[mode], float(g), dpred)
+    return loss, dpred
+
+
+def spectral_reg(w, u0, alpha=10.0):
+    """layers/spectralnorm.py:216-239 -> (loss[1], sgn[1]); gradient via spectral_reg_grad."""
+    K = w.numel() // w.shape[-1]
+    Nn = w.shape[-1]
+    assert u0.numel() == K
+    loss, sgn = _new((1,), w), _new((1,), w)
+    ws = _ws('spectral', N.call('mmseg_spectral_workspace_floats', K, Nn), w.device)
+    N.call('mmseg_spectral_fwd', w, u0, loss, sgn, ws, K, Nn, float(alpha))
+    return loss, sgn
+
+
+def spectral_reg_grad(w, sgn, scale=1.0):
+    dw = _new(w.shape, w)
+    N.call('mmseg_spectral_grad', w, sgn, float(scale), w.numel(), dw)
+    return dw
+
+
+def adam_step(p, g, m, v, lr_t, beta_1=0.9, beta_2=0.999, eps=1e-7):
+    """Keras 2.1.6 Adam over flat arenas (p, g, m, v: 1-D views of equal length)."""
+    assert p.numel() == g.numel() == m.numel() == v.numel()
+    N.call('mmseg_adam', p, g, m, v, p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps))
+
+
+def fill_(t, value):
+    N.call('mmseg_fill', t, t.numel(), float(value))
+    return t
+
+
+def axpby(a, b, sa=1.0, sb=1.0, out=None):
+    out = _new(a.shape, a) if out is None else out
+    N.call('mmseg_axpby', _c(a), _c(b), out, a.numel(), float(sa), float(sb))
+    return out

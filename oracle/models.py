@@ -312,7 +312,8 @@ def anatomy_fuser(a1, a2, P):
     """-> (a1 deformed onto a2, max(a1_deformed, a2))  (anatomy_fuser.py:28-35)."""
     theta = locnet(a1, a2, P)
     a1_def = O.tps_warp(a1, theta)
-    return a1_def, torch.maximum(a1_def, a2)
+    # keras Maximum = tf.maximum: value max, gradient ties go to the FIRST argument (dd)
+    return a1_def, torch.where(a1_def >= a2, a1_def, a2)
 
 
 # ----------------------------------------------------------------------------

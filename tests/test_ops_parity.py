@@ -1,0 +1,300 @@
+"""Op-level parity: every operator of multimodal_segmentation_amd.ops (forward and backward through the C ABI)
+against the oracle on the same seeded inputs.
+
+  * `-m gpu`     : the real libmmseg_hip.so on cuda:0 (the parity tests proper);
+  * `-m "not gpu"`: the same cases through tests/cpu_backend.py, which checks the host-side autograd glue.
+Tolerances: fp32 accumulation over K <= 4608 terms -> 2e-4 relative to the tensor's max magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+from multimodal_segmentation_amd import ops as P
+
+RTOL = 2e-4
+
+
+def _dev(request):
+    return request.param
+
+
+def _close(a, b, name, rtol=RTOL):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, '%s: shape %s vs %s' % (name, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale + 1e-7, '%s: max err %.3e (scale %.3e)' % (name, err, scale)
+
+
+def check(f_prod, f_ref, inputs, device, grad_mask=None, rtol=RTOL):
+    """inputs: list of CPU fp32 tensors.  Runs both functions, a random cotangent, and compares outputs and the
+    gradients of every input with grad_mask[i] true."""
+    grad_mask = grad_mask or [True] * len(inputs)
+    xs_p = [t.clone().to(device).requires_grad_(m) for t, m in zip(inputs, grad_mask)]
+    xs_r = [t.clone().double().requires_grad_(m) for t, m in zip(inputs, grad_mask)]
+    yp = f_prod(*xs_p)
+    yr = f_ref(*xs_r)
+    yp = yp if isinstance(yp, (tuple, list)) else [yp]
+    yr = yr if isinstance(yr, (tuple, list)) else [yr]
+    g = torch.Generator().manual_seed(123)
+    cots = [torch.randn(y.shape, generator=g) for y in yr]
+    pre = getattr(f_ref, 'pre', None)
+    if pre is not None:   # no cotangent where the activation kink could flip between fp32 and fp64
+        cots[0] = cots[0] * (pre.detach().abs() > 1e-4).float()
+    for i, (a, b) in enumerate(zip(yp, yr)):
+        _close(a, b, 'out%d' % i, rtol)
+    torch.autograd.backward(list(yp), [c.to(device) for c in cots])
+    torch.autograd.backward(list(yr), [c.double() for c in cots])
+    for i, m in enumerate(grad_mask):
+        if m:
+            assert xs_p[i].grad is not None, 'no grad for input %d' % i
+            _close(xs_p[i].grad, xs_r[i].grad, 'grad%d' % i, rtol)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+DEVICES = [pytest.param('cpu', id='cpu-standin'), pytest.param('cuda', marks=pytest.mark.gpu, id='mi355x')]
+
+
+@pytest.fixture(params=DEVICES)
+def device(request):
+    if request.param == 'cpu':
+        from tests import cpu_backend as cb
+        cb.install()
+        yield 'cpu'
+        cb.uninstall()
+    else:
+        assert torch.cuda.is_available(), 'gpu-marked test needs a GPU'
+        yield 'cuda'
+
+
+# B, H, W, C1, C2, Cout, k, stride, padding, act, ups
+CONV_CASES = [
+    (2, 16, 16, 64, 0, 64, 3, 1, 'same', None, False),
+    (2, 20, 12, 1, 0, 64, 3, 1, 'same', 'relu', False),
+    (2, 16, 16, 8, 0, 8, 3, 1, 'same', 'leaky', False),
+    (1, 16, 16, 64, 64, 64, 3, 1, 'same', None, False),
+    (2, 16, 16, 128, 0, 64, 3, 1, 'same', None, True),
+    (2, 33, 33, 8, 1, 16, 3, 2, 'valid', 'leaky', False),
+    (2, 34, 30, 4, 0, 64, 4, 2, 'valid', 'leaky', False),
+    (2, 16, 16, 64, 0, 128, 4, 2, 'valid', 'leaky', False),
+    (2, 9, 9, 64, 0, 128, 4, 1, 'valid', 'leaky', False),
+    (2, 20, 20, 8, 8, 20, 5, 1, 'valid', 'leaky', False),
+    (2, 16, 16, 64, 0, 8, 1, 1, 'same', None, False),
+    (2, 16, 16, 64, 0, 5, 1, 1, 'same', None, False),
+    (2, 16, 16, 8, 0, 1, 1, 1, 'same', 'tanh', False),
+    (1, 12, 12, 1, 0, 64, 4, 2, 'valid', 'leaky', False),
+    (2, 8, 8, 256, 0, 512, 3, 1, 'same', None, False),
+    (3, 128, 128, 64, 0, 128, 3, 1, 'same', 'relu', False),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d(case, device):
+    B, H, W, C1, C2, Cout, k, stride, padding, act, ups = case
+    alpha = 0.2 if act == 'leaky' else 0.0
+    x1 = rnd(B, H // 2 if ups else H, W // 2 if ups else W, C1, seed=1)
+    w = rnd(k, k, C1 + C2, Cout, seed=2, scale=(2.0 / (k * k * (C1 + C2))) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    inputs = [x1, w, b] + ([rnd(B, H, W, C2, seed=4)] if C2 else [])
+
+    def f_prod(x1, w, b, x2=None):
+        return P.conv2d(x1, w, b, stride=stride, padding=padding, act=act, alpha=alpha, x2=x2, upsample=ups)
+
+    def f_ref(x1, w, b, x2=None):
+        xin = O.upsample2(x1) if ups else x1
+        if x2 is not None:
+            xin = torch.cat([xin, x2], -1)
+        y = O.conv2d(xin, w, b, stride=stride, padding=padding)
+        f_ref.pre = y
+        if act == 'relu':
+            y = torch.relu(y)
+        elif act == 'leaky':
+            y = O.leaky_relu(y, alpha)
+        elif act == 'tanh':
+            y = torch.tanh(y)
+        return y
+
+    check(f_prod, f_ref, inputs, device)
+
+
+@pytest.mark.parametrize('shape,relu', [((2, 16, 16, 64), True), ((3, 8, 8, 128), False), ((2, 32, 32, 64), True)])
+def test_batchnorm_train(shape, relu, device):
+    C = shape[-1]
+    x = rnd(*shape, seed=5) * 2 + 3.0          # non-zero mean: exercises the shifted-sum variance
+    gamma, beta = rnd(C, seed=6) * 0.2 + 1, rnd(C, seed=7) * 0.2
+    mm0, mv0 = rnd(C, seed=8) * 0.1, torch.rand(C) + 0.5
+    mm_p, mv_p = mm0.clone().to(device), mv0.clone().to(device)
+    Pd = {}
+
+    def f_prod(x, g, b):
+        return P.batchnorm(x, g, b, mm_p, mv_p, True, relu)
+
+    def f_ref(x, g, b):
+        Pd.update({'n/gamma': g, 'n/beta': b, 'n/moving_mean': mm0.double(), 'n/moving_variance': mv0.double()})
+        upd = []
+        y = O.batchnorm(x, Pd, 'n', True, upd)
+        O.apply_bn_updates(Pd, upd)
+        f_ref.pre = y
+        return torch.relu(y) if relu else y
+
+    check(f_prod, f_ref, [x, gamma, beta], device, rtol=5e-4)
+    _close(mm_p, Pd['n/moving_mean'], 'moving_mean')
+    _close(mv_p, Pd['n/moving_variance'], 'moving_variance')
+
+
+def test_batchnorm_infer(device):
+    C = 64
+    x = rnd(2, 8, 8, C, seed=9)
+    g, b, mm, mv = rnd(C, seed=1) + 1, rnd(C, seed=2), rnd(C, seed=3), torch.rand(C) + 0.5
+    y = P.batchnorm(x.to(device), g.to(device), b.to(device), mm.to(device), mv.to(device), False, True)
+    Pd = {'n/gamma': g, 'n/beta': b, 'n/moving_mean': mm, 'n/moving_variance': mv}
+    _close(y, torch.relu(O.batchnorm(x, Pd, 'n', False)), 'bn_infer')
+
+
+def test_maxpool(device):
+    x = rnd(2, 16, 12, 64, seed=10)
+    x[0, :4, :4] = 0.0   # ties: gradient must go to the first maximum
+    check(P.maxpool2, O.maxpool2, [x], device)
+
+
+@pytest.mark.parametrize('C', [8, 5])
+def test_softmax_round(C, device):
+    x = rnd(2, 16, 16, C, seed=11) * 3
+
+    def f_prod(x):
+        p, s = P.softmax_round(x)
+        return p, s
+
+    def f_ref(x):
+        p = torch.softmax(x, -1)
+        return p, O.round_ste(p)
+
+    check(f_prod, f_ref, [x], device)
+
+
+@pytest.mark.parametrize('R,K,N,act', [(8, 28800, 32, 'leaky'), (8, 32, 8, None), (8, 1000, 100, 'tanh'),
+                                       (8, 8, 2048, None), (8, 5000, 1, None), (16, 300, 50, None)])
+def test_dense(R, K, N, act, device):
+    x, w, b = rnd(R, K, seed=12), rnd(K, N, seed=13, scale=K ** -0.5), rnd(N, seed=14, scale=0.1)
+
+    def f_ref(x, w, b):
+        y = O.dense(x, w, b)
+        return O.leaky_relu(y, 0.3) if act == 'leaky' else (torch.tanh(y) if act == 'tanh' else y)
+
+    check(lambda x, w, b: P.dense(x, w, b, act, 0.3), f_ref, [x, w, b], device)
+
+
+def test_film(device):
+    x, g, b, r = rnd(2, 16, 16, 8, seed=15), rnd(2, 8, seed=16), rnd(2, 8, seed=17), rnd(2, 16, 16, 8, seed=18)
+    check(lambda x, g, b, r: P.film(x, g, b, r, 0.3),
+          lambda x, g, b, r: O.leaky_relu(O.film(x, g, b), 0.3) + r, [x, g, b, r], device)
+
+
+def test_tps_warp(device):
+    B, H, W, C = 2, 24, 20, 8
+    vol = (torch.rand(B, H, W, C, generator=torch.Generator().manual_seed(19)) > 0.5).float() + rnd(B, H, W, C, seed=20) * 0.1
+    theta = rnd(B, 25, 2, seed=21, scale=0.05)
+    Mb = O.tps_basis(H, W)
+
+    def f_prod(vol, theta):
+        return P.tps_warp(vol, theta, Mb.float().to(vol.device))
+
+    check(f_prod, lambda v, t: O.tps_warp(v, t), [vol, theta], device, rtol=1e-3)
+
+
+def test_tps_identity(device):
+    """KAT: theta = 0 is the identity warp (the Dense producing theta is zero-initialised, stn_spline.py:116)."""
+    B, H, W, C = 1, 16, 16, 8
+    vol = rnd(B, H, W, C, seed=22)
+    out = P.tps_warp(vol.to(device), torch.zeros(B, 25, 2, device=device), O.tps_basis(H, W).float().to(device))
+    _close(out, vol, 'identity', rtol=1e-5)
+
+
+def test_maximum_slice_sampling_add(device):
+    a = (rnd(2, 8, 8, 8, seed=23) > 0).float()
+    b = (rnd(2, 8, 8, 8, seed=24) > 0).float()      # many exact ties
+    check(P.maximum, lambda a, b: torch.where(a >= b, a, b), [a, b], device)
+    x = rnd(2, 8, 8, 5, seed=25)
+    check(lambda x: P.slice_channels(x, 0, 4), lambda x: x[..., 0:4], [x], device)
+    mu, lv, eps = rnd(8, 8, seed=26), rnd(8, 8, seed=27) * 0.3, rnd(8, 8, seed=28)
+    check(lambda m, l: P.sampling_kl(m, l, eps.to(m.device)), lambda m, l: (O.sampling(m, l, eps.double()), O.kl(m, l)),
+          [mu, lv], device)
+    check(P.add, lambda a, b: a + b, [a, x.new_ones(a.shape)], device)
+
+
+@pytest.mark.parametrize('with_mod,act_alpha', [(True, 0.2), (True, -1.0), (False, -1.0)])
+def test_instnorm_spade(with_mod, act_alpha, device):
+    x = rnd(2, 8, 8, 16, seed=29) * 2 + 1
+    ins = [x] + ([rnd(2, 8, 8, 16, seed=30) * 0.3, rnd(2, 8, 8, 16, seed=31) * 0.3] if with_mod else [])
+
+    def f_ref(x, g=None, b=None):
+        v = O.instance_norm(x)
+        if g is not None:
+            v = O.spade_cond(v, g, b)
+        return O.leaky_relu(v, act_alpha) if act_alpha >= 0 else v
+
+    check(lambda x, g=None, b=None: P.instnorm_spade(x, g, b, act_alpha), f_ref, ins, device, rtol=5e-4)
+
+
+def _masks(B, H, W, nm, seed):
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.randint(0, nm + 1, (B, H, W), generator=g)
+    return torch.nn.functional.one_hot(lab, nm + 1).float()
+
+
+@pytest.mark.parametrize('lam', [0.01, 0.0])
+def test_seg_loss(lam, device):
+    B, H, W, nm = 2, 16, 16, 4
+    t = _masks(B, H, W, nm, 32)
+    pred = torch.softmax(rnd(B, H, W, nm + 1, seed=33), -1)
+    pr = pred.clone().double().requires_grad_(True)
+    ref = O.combined_dice_bce(t.double(), pr, nm) if lam else O.dice_loss(t.double(), pr, nm)
+    (gref,) = torch.autograd.grad(ref * 10.0, pr)
+    loss, dp = P.seg_loss(pred.to(device), t.to(device), nm, lam, 10.0)
+    _close(loss, ref.reshape(1), 'loss', 1e-5)
+    _close(dp, gref, 'dpred', 1e-4)
+
+
+@pytest.mark.parametrize('mode', ['mae', 'mse', 'mean'])
+def test_diff_loss(mode, device):
+    p, t = rnd(2, 8, 8, 3, seed=34), rnd(2, 8, 8, 3, seed=35)
+    pr = p.clone().double().requires_grad_(True)
+    ref = {'mae': O.mae(t.double(), pr), 'mse': O.mse(t.double(), pr), 'mean': pr.mean()}[mode]
+    (gref,) = torch.autograd.grad(ref * 0.5, pr)
+    loss, dp = P.diff_loss(p.to(device), t.to(device), mode, 0.5)
+    _close(loss, ref.reshape(1), 'loss', 1e-5)
+    _close(dp, gref, 'grad', 1e-5)
+    loss1, _ = P.diff_loss(p.to(device), 1.0, 'mse', 1.0)
+    _close(loss1, O.mse(torch.ones_like(p), p).reshape(1), 'mse-const', 1e-5)
+
+
+def test_spectral_reg(device):
+    w = rnd(4, 4, 16, 32, seed=36, scale=0.1)
+    u0 = torch.rand(256, 1, generator=torch.Generator().manual_seed(37)) * 2 - 1
+    wr = w.clone().double().requires_grad_(True)
+    ref = O.spectral_reg(wr, u0.double(), 10.0)
+    (gref,) = torch.autograd.grad(ref, wr)
+    loss, sgn = P.spectral_reg(w.to(device), u0.to(device), 10.0)
+    _close(loss, ref.reshape(1), 'loss', 1e-4)
+    _close(P.spectral_reg_grad(w.to(device), sgn), gref, 'grad', 1e-5)
+
+
+def test_adam(device):
+    n = 1003
+    p, g = rnd(n, seed=38), rnd(n, seed=39)
+    Pd = {'p': p.clone().double()}
+    opt = O.KerasAdam(1e-3)
+    pp, m, v = p.clone().to(device), torch.zeros(n, device=device), torch.zeros(n, device=device)
+    import math
+    for t in range(1, 4):
+        gt = g * t
+        opt.step(Pd, {'p': gt.double()})
+        lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        P.adam_step(pp, gt.to(device), m, v, lr_t)
+    _close(pp, Pd['p'], 'adam', 1e-6)
