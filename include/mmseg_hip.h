@@ -66,6 +66,11 @@ int mmseg_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, voi
 int mmseg_maxpool2_bwd(const float* x, const float* y, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
 /* gradient of keras UpSampling2D(2): dx[B,H,W,C] = 2x2 block sums of dy[B,2H,2W,C] */
 int mmseg_upsample2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+/* keras UpSampling2D(2) standalone (decoder.py:70-80): y[B,2H,2W,C] */
+int mmseg_upsample2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+/* tf.image.resize_nearest_neighbor for an integer down-sampling factor f (layers/spade.py:36-38): y[B,Ho,Wo,C] */
+int mmseg_subsample_fwd(const float* x, float* y, int B, int Ho, int Wo, int C, int f, void* stream);
+int mmseg_subsample_bwd(const float* dy, float* dx, int B, int Ho, int Wo, int C, int f, void* stream);
 /* channel softmax; s (optional) = round-half-even(p): conv_anatomy softmax + layers/rounding.py:23-42 */
 int mmseg_softmax_fwd(const float* x, float* p, float* s, long npix, int C, void* stream);
 int mmseg_softmax_bwd(const float* dy, const float* p, float* dx, long npix, int C, void* stream);

@@ -291,6 +291,41 @@ __global__ void sampling_kl_bwd_kernel(const float* __restrict__ mu, const float
     dlv[i] = gz * 0.5f * expf(0.5f * l) * eps[i] + gk * (-0.5f) * (1.f - expf(l));
 }
 
+// ---- nearest resampling ------------------------------------------------------------------------------------
+// keras UpSampling2D(2) as a standalone op (SPADE decoder, decoder.py:70-80): y[B,2H,2W,C]
+__global__ void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4) {
+    const long n = (long)B * 2 * H * 2 * W * C4;
+    const f32x4* X = reinterpret_cast<const f32x4*>(x);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4; long r = i / C4;
+        const int w = r % (2 * W); r /= (2 * W);
+        const int h = r % (2 * H); const int b = r / (2 * H);
+        reinterpret_cast<f32x4*>(y)[i] = X[(((long)b * H + (h >> 1)) * W + (w >> 1)) * C4 + c];
+    }
+}
+// tf.image.resize_nearest_neighbor(align_corners=False) for an integer down-sampling factor f (layers/spade.py:36-38):
+// y[b, i, j, :] = x[b, i*f, j*f, :]
+__global__ void subsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int Ho, int Wo, int C, int f) {
+    const long n = (long)B * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C; long r = i / C;
+        const int w = r % Wo; r /= Wo;
+        const int h = r % Ho; const int b = r / Ho;
+        y[i] = x[(((long)b * Ho * f + (long)h * f) * Wo * f + (long)w * f) * C + c];
+    }
+}
+// dx[B, Ho*f, Wo*f, C]: dy at the sampled positions, 0 elsewhere
+__global__ void subsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int Ho, int Wo, int C, int f) {
+    const int H = Ho * f, W = Wo * f;
+    const long n = (long)B * H * W * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C; long r = i / C;
+        const int w = r % W; r /= W;
+        const int h = r % H; const int b = r / H;
+        dx[i] = (h % f == 0 && w % f == 0) ? dy[(((long)b * Ho + h / f) * Wo + w / f) * C + c] : 0.f;
+    }
+}
+
 extern "C" {
 
 int mmseg_act_fwd(const float* x, float* y, long n, int act, float alpha, void* stream) {
@@ -342,6 +377,23 @@ int mmseg_upsample2_bwd(const float* dy, float* dx, int B, int H, int W, int C, 
     if (C & 3) return (int)hipErrorInvalidValue;
     const long n = (long)B * H * W * (C / 4);
     hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C / 4);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_upsample2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    const long n = (long)B * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_subsample_fwd(const float* x, float* y, int B, int Ho, int Wo, int C, int f, void* stream) {
+    if (f < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(subsample_fwd_kernel, dim3(grid_for((long)B * Ho * Wo * C, 256)), dim3(256), 0, (hipStream_t)stream, x, y, B, Ho, Wo, C, f);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_subsample_bwd(const float* dy, float* dx, int B, int Ho, int Wo, int C, int f, void* stream) {
+    if (f < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(subsample_bwd_kernel, dim3(grid_for((long)B * Ho * f * Wo * f * C, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, Ho, Wo, C, f);
     return MMSEG_CHECK_LAUNCH();
 }
 

@@ -1,0 +1,65 @@
+"""SPADE conditioning and the SPADE decoder body (reference layers/spade.py:7-58, model_components/decoder.py:67-81).
+
+_spade: InstanceNorm(no affine) over (H,W,C) -> nearest-resize the anatomy to the layer's size -> conv3x3 8->128 ReLU
+-> conv3x3 128->f (gamma), 128->f (beta) -> x*(1+gamma)+beta.  spade_block: SPADE -> LeakyReLU(0.2) -> conv3x3 ->
+SPADE -> LeakyReLU(0.2) -> conv3x3 (+ SPADE -> conv1x1 no-bias shortcut when fin != fout) -> Add.
+InstanceNorm + modulation + LeakyReLU are one fused kernel (csrc/norm.hip).
+"""
+from .. import nn, ops
+
+SPADE_BLOCKS = ((128, 128), (128, 128), (128, 128), (128, 64), (64, 32), (32, 16))
+
+
+def _declare_spade(m, name, f, s_ch):
+    nn.conv_params(m, name + '_shared', 3, s_ch, 128)
+    nn.conv_params(m, name + '_gamma', 3, 128, f)
+    nn.conv_params(m, name + '_beta', 3, 128, f)
+
+
+def declare_spade_decoder(m, conf):
+    H, W = conf.input_shape[0], conf.input_shape[1]
+    if H % 32 or W % 32:
+        raise ValueError('SPADE decoder needs H, W multiples of 32 (decoder.py:68-69)')
+    s_ch = conf.anatomy_encoder.output_shape[-1]
+    nn.dense_params(m, 'fc', conf.num_z, H * W * 128 // 1024)
+    for i, (fin, fout) in enumerate(SPADE_BLOCKS):
+        n = 'b%d' % i
+        fmid = min(fin, fout)
+        _declare_spade(m, n + '_s0', fin, s_ch); nn.conv_params(m, n + '_c0', 3, fin, fmid)
+        _declare_spade(m, n + '_s1', fmid, s_ch); nn.conv_params(m, n + '_c1', 3, fmid, fout)
+        if fin != fout:
+            _declare_spade(m, n + '_ss', fin, s_ch); nn.conv_params(m, n + '_cs', 1, fin, fout, bias=False)
+    return SPADE_BLOCKS[-1][1]
+
+
+def _spade(m, name, anatomy_input, layer, act_alpha):
+    """layers/spade.py:26-33 (+ the LeakyReLU that follows it in spade_block when act_alpha >= 0)"""
+    a = ops.resize_nearest_down(anatomy_input, layer.shape[1], layer.shape[2])
+    a = nn.conv(m, name + '_shared', a, act='relu')
+    gamma = nn.conv(m, name + '_gamma', a)
+    beta = nn.conv(m, name + '_beta', a)
+    return ops.instnorm_spade(layer, gamma, beta, act_alpha)
+
+
+def spade_block(m, n, anatomy_input, layer, fin, fout):
+    """layers/spade.py:7-23"""
+    l2 = _spade(m, n + '_s0', anatomy_input, layer, 0.2)
+    l3 = nn.conv(m, n + '_c0', l2)
+    l5 = _spade(m, n + '_s1', anatomy_input, l3, 0.2)
+    l6 = nn.conv(m, n + '_c1', l5)
+    if fin != fout:
+        layer = _spade(m, n + '_ss', anatomy_input, layer, -1.0)
+        layer = nn.conv(m, n + '_cs', layer)
+    return ops.add(layer, l6)
+
+
+def spade_decoder(m, conf, anatomy_input, modality_input):
+    """decoder.py:67-81"""
+    B = anatomy_input.shape[0]
+    H, W = conf.input_shape[0], conf.input_shape[1]
+    l = nn.dense(m, 'fc', modality_input).reshape(B, H // 32, W // 32, 128)
+    for i, (fin, fout) in enumerate(SPADE_BLOCKS):
+        if i > 0:
+            l = ops.upsample2(l)
+        l = spade_block(m, 'b%d' % i, anatomy_input, l, fin, fout)
+    return l

@@ -1,0 +1,79 @@
+"""Anatomy encoders (reference model_components/anatomy_encoder.py).
+
+build(conf, name)                 : one full UNet per modality (MMSDNet; anatomy_encoder.py:13-30)
+AnatomyEncoders(mods).build(conf) : two per-modality down paths + ONE shared bottleneck / up path / conv_anatomy
+                                    (DAFNet; anatomy_encoder.py:32-155)
+Output: s = Rounding(softmax(conv1x1(features))) in {0,1}^{HxWx8}; the pre-rounding softmax is kept on the model
+as `.last_soft` (used for teacher-forced parity checks across the rounding discontinuity).
+"""
+import logging
+
+from .. import nn, ops
+from ..models import unet
+from ..utils.rng import global_rng
+
+log = logging.getLogger('anatomy_encoder')
+
+
+def _check(conf):
+    if conf.normalise != 'batch':
+        raise NotImplementedError("anatomy encoder: only normalise='batch' (the value of every reference config)")
+    if not (1 <= conf.downsample <= 4):
+        raise ValueError('Unet downsample must be in 1..4')
+
+
+class SharedDecoder(nn.Model):
+    """AnatomyEncoders.build_decoder (anatomy_encoder.py:104-155): layers l0_1 .. l40 + the shared conv_anatomy."""
+
+    def __init__(self, conf, rng, name='Enc_Anatomy_shared'):
+        super(SharedDecoder, self).__init__(name)
+        unet.declare_unet_up(self, conf.filters, conf.out_channels, conf.downsample)
+        self.finalize(rng)
+
+
+class AnatomyEncoder(nn.Model):
+    """x [B,H,W,1] -> s [B,H,W,out_channels].  `shared`: a SharedDecoder whose weights are used (and reported by
+    get_weights) instead of an own bottleneck/up path."""
+
+    def __init__(self, conf, rng, name, shared=None):
+        super(AnatomyEncoder, self).__init__(name)
+        _check(conf)
+        self.conf = conf
+        unet.declare_unet_down(self, conf.input_shape[-1], conf.filters, conf.downsample)
+        if shared is None:
+            unet.declare_unet_up(self, conf.filters, conf.out_channels, conf.downsample)
+            self.up = self
+        else:
+            self.up = shared
+            self.shared = [shared]
+        self.finalize(rng)
+        self.input_shape = (None,) + tuple(conf.input_shape)
+        self.output_shape = (None,) + tuple(conf.output_shape)
+        self.last_soft = None
+
+    def forward(self, x, training=False):
+        ds = self.conf.downsample
+        l, skips = unet.unet_downsample(self, x, training, ds)
+        l = unet.unet_bottleneck_upsample(self.up, l, skips, training, ds)
+        logits = nn.conv(self.up, 'conv_anatomy', l)
+        soft, rounded = ops.softmax_round(logits)        # Conv2D(.., softmax) + Rounding (anatomy_encoder.py:23-25)
+        self.last_soft = soft
+        return rounded if self.conf.rounding else soft
+
+
+def build(conf, name='Enc_Anatomy', rng=None):
+    """Build a UNet based encoder to extract anatomical information from the image."""
+    model = AnatomyEncoder(conf, rng or global_rng(), name)
+    log.info('Enc_Anatomy')
+    model.summary(print_fn=log.debug)
+    return model
+
+
+class AnatomyEncoders(object):
+    def __init__(self, modalities):
+        self.modalities = modalities
+
+    def build(self, conf, rng=None):
+        rng = rng or global_rng()
+        shared = SharedDecoder(conf, rng)
+        return [AnatomyEncoder(conf, rng, 'Enc_Anatomy_%s' % mod, shared) for mod in self.modalities[:2]]

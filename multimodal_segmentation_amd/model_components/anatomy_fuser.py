@@ -1,0 +1,34 @@
+"""Anatomy fuser: deform anatomy1 onto anatomy2 with a thin-plate-spline STN, then fuse with a pixel-wise max
+(reference model_components/anatomy_fuser.py:12-38, layers/stn_spline.py)."""
+import logging
+
+from .. import nn, ops
+from ..layers import stn_spline
+from ..utils.rng import global_rng
+
+log = logging.getLogger('anatomy_fuser')
+
+
+class AnatomyFuser(nn.Model):
+    def __init__(self, conf, rng):
+        super(AnatomyFuser, self).__init__('Anatomy_Fuser')
+        shp = conf.anatomy_encoder.output_shape
+        self.cp = [5, 5]
+        stn_spline.declare_locnet(self, shp, shp, self.cp[0] * self.cp[1] * 2)
+        self.finalize(rng)
+        self.tps = stn_spline.ThinPlateSpline2D(shp[:-1], self.cp, shp[-1])
+        self.output_shape = [(None,) + tuple(shp)] * 2
+
+    def forward(self, anatomy1, anatomy2, training=False):
+        theta = stn_spline.locnet(self, anatomy1, anatomy2)
+        anatomy1_deformed = self.tps([anatomy1, theta])
+        anatomy_fused = ops.maximum(anatomy1_deformed, anatomy2)      # keras.layers.Maximum (anatomy_fuser.py:33)
+        self.last_theta = theta
+        return [anatomy1_deformed, anatomy_fused]
+
+
+def build(conf, rng=None):
+    model = AnatomyFuser(conf, rng or global_rng())
+    log.info('Anatomy fuser')
+    model.summary(print_fn=log.debug)
+    return model

@@ -1,0 +1,58 @@
+"""Modality (intensity) encoder: (anatomy, image) -> (z, KL) (reference model_components/modality_encoder.py:13-52).
+
+4 x [conv3x3 stride 2 valid + LeakyReLU(0.3)] -> Flatten -> Dense 32 + LeakyReLU -> z_mean, z_log_var (Dense num_z)
+-> z = mean + exp(0.5 log_var) * eps (utils/sdnet_utils.py:9-21), KL (costs.py:186-189).  The Concatenate of the
+9 input channels is folded into the first convolution's gather.  `mu_only=True` is the reference's Enc_Modality_mu
+sub-model cut at layer `z_mean` (models/dafnet.py:126).
+"""
+import logging
+
+import numpy as np
+import torch
+
+from .. import nn, ops
+from ..utils.rng import global_rng
+
+log = logging.getLogger('modality_encoder')
+
+
+class ModalityEncoder(nn.Model):
+    def __init__(self, conf, rng):
+        super(ModalityEncoder, self).__init__('Enc_Modality')
+        self.conf = conf
+        H, W, sc = conf.anatomy_encoder.output_shape
+        c = sc + conf.input_shape[-1]
+        for i, f in enumerate((16, 32, 64, 128)):
+            nn.conv_params(self, 'c%d' % i, 3, c, f, 'he_normal')
+            c = f
+            H, W = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+        nn.dense_params(self, 'd0', H * W * c, 32, 'he_normal')
+        nn.dense_params(self, 'z_mean', 32, conf.num_z)
+        nn.dense_params(self, 'z_log_var', 32, conf.num_z)
+        self.finalize(rng)
+        self.output_shape = [(None, conf.num_z), (None, 1)]
+
+    def _mean_logvar(self, s, x):
+        l = nn.conv(self, 'c0', s, stride=2, padding='valid', act='leaky', alpha=0.3, x2=x)
+        for i in (1, 2, 3):
+            l = nn.conv(self, 'c%d' % i, l, stride=2, padding='valid', act='leaky', alpha=0.3)
+        l = nn.dense(self, 'd0', l.reshape(l.shape[0], -1), act='leaky', alpha=0.3)
+        return nn.dense(self, 'z_mean', l), nn.dense(self, 'z_log_var', l)
+
+    def forward(self, s, x, training=False, eps=None, mu_only=False):
+        z_mean, z_log_var = self._mean_logvar(s, x)
+        if mu_only:
+            return z_mean
+        if eps is None:     # K.random_normal inside the graph (sdnet_utils.py:20): drawn on the host like z samples
+            eps = np.random.normal(0., 1., size=tuple(z_mean.shape)).astype(np.float32)
+        eps = nn.to_device(eps, z_mean.device)
+        z, kl = ops.sampling_kl(z_mean, z_log_var, eps)
+        return [z, kl]
+
+
+def build(conf, rng=None):
+    """Build an encoder to extract intensity information from the image."""
+    model = ModalityEncoder(conf, rng or global_rng())
+    log.info('Enc_Modality')
+    model.summary(print_fn=log.debug)
+    return model

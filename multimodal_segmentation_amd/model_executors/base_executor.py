@@ -1,0 +1,70 @@
+"""Base class of the executors (reference model_executors/base_executor.py): batch alignment, the background
+("residual") mask channel, data iterators.  Augmentation (keras ImageDataGenerator, rotation +-20 degrees,
+base_executor.py:37-78,103-110) is a "next" row: the iterators below shuffle and batch only."""
+import logging
+
+import numpy as np
+
+log = logging.getLogger('executor')
+
+
+class Executor(object):
+    def __init__(self, conf, model):
+        self.conf = conf
+        self.model = model
+        self.loader = model.loader
+        self.epoch = 0
+        self.batch = 0
+        self.batches = 0
+
+    def add_residual(self, data):
+        """reference base_executor.py:83-87"""
+        residual = np.ones(data.shape[:-1] + (1,))
+        for i in range(data.shape[-1]):
+            residual[data[..., i:i + 1] == 1] = 0
+        return np.concatenate([data, residual], axis=-1)
+
+    def align_batches(self, array_list):
+        """reference base_executor.py:112-119"""
+        mn = np.min([x.shape[0] for x in array_list])
+        return [x[0:mn] + 0. for x in array_list]
+
+    @staticmethod
+    def batch_iterator(arrays, batch_size, rng):
+        """Infinite iterator over aligned arrays: reshuffles every pass, yields tuples of batches (the last batch of
+        a pass may be smaller, like keras' NumpyArrayIterator)."""
+        n = arrays[0].shape[0]
+        while True:
+            order = rng.permutation(n)
+            for i in range(0, n, batch_size):
+                idx = order[i:i + batch_size]
+                out = tuple(a[idx] for a in arrays)
+                yield out if len(out) > 1 else out[0]
+
+    def validate(self, epoch_loss):
+        pass
+
+    def stop_criterion(self, es, logs):
+        es.on_epoch_end(self.epoch, logs)
+        return es.stopped_epoch > 0
+
+
+class EarlyStopping(object):
+    """keras.callbacks.EarlyStopping(monitor, min_delta, patience), mode 'min' (dafnet_executor.py:222)"""
+
+    def __init__(self, monitor, min_delta=0., patience=0):
+        self.monitor, self.min_delta, self.patience = monitor, min_delta, patience
+        self.best = np.inf
+        self.wait = 0
+        self.stopped_epoch = 0
+
+    def on_epoch_end(self, epoch, logs):
+        cur = logs.get(self.monitor)
+        if cur is None:
+            return
+        if cur < self.best - self.min_delta:
+            self.best, self.wait = cur, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                self.stopped_epoch = epoch

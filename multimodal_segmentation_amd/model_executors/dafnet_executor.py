@@ -1,0 +1,308 @@
+"""DAFNet executor: the epoch / batch loop and the per-iteration schedule (reference
+model_executors/dafnet_executor.py).
+
+One iteration (`train_batch`, dafnet_executor.py:369-387), expert pairing:
+  l_mix > 0 : supervised_trainer.fit  -> D_Mask_trainer.fit x2 -> D_Image1_trainer.fit, D_Image2_trainer.fit
+  l_mix < 1 : unsupervised_trainer.fit -> the same three discriminator phases again
+The reference performs 20 `predict` + 5 `fit` host<->device round trips per pass; here every tensor stays in HBM:
+the fake pools are generated (in `predict` mode, i.e. with the moving BatchNorm statistics), concatenated and
+sampled on the device, only the random draws (z, eps, pool indices) are made on the host with numpy exactly like the
+reference (utils/distributions.py:9-11, utils/data_utils.py:125-129), and no loss value is read back unless asked.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+
+from .. import costs, nn
+from ..loaders import synthetic
+from ..utils import data_utils
+from ..utils.distributions import NormalDistribution
+from .base_executor import Executor, EarlyStopping
+
+log = logging.getLogger('dafnet_executor')
+
+
+class DAFNetExecutor(Executor):
+    """Train a DAFNet model using parameters stored in the configuration."""
+
+    def __init__(self, conf, model):
+        super(DAFNetExecutor, self).__init__(conf, model)
+        self.gen_labelled = None          # iterator for labelled data (supervised learning)
+        self.gen_unlabelled = None        # iterator for unlabelled data (unsupervised learning)
+        self.discriminator_masks = None   # iterator for real masks to train discriminators
+        self.discriminator_image = None   # iterators for images to train discriminators
+        self.data = None
+        self.ul_data = None
+        self.device = model.D_Mask.device
+        self.keep_losses_on_device = False
+
+    # ---- data ----------------------------------------------------------------------------------------------------
+    def init_train_data(self, device_resident=True, slices_per_volume=20, data_seed=1234):
+        """Synthetic CHAOS-like split: round(l_mix * 14) labelled volumes (dafnet_executor.py:88,139), the rest
+        unlabelled; data seed 1234 + rank."""
+        from ..parallel import dp
+        sp = synthetic.splits()
+        n_lab = int(round(float(self.conf.l_mix) * len(sp['training'])))
+        shp, nm = self.conf.input_shape, self.conf.num_masks
+        seed = data_seed + dp.rank()
+        lab_vols = sp['training'][:max(n_lab, 1)]
+        self.data = synthetic.SyntheticPairedData(shp, nm, lab_vols, slices_per_volume, seed)
+        ul_vols = sp['training'][n_lab:] if n_lab < len(sp['training']) else []
+        self.ul_data = synthetic.SyntheticPairedData(shp, nm, ul_vols, slices_per_volume, seed + 1) if ul_vols else None
+        self.val_data = synthetic.SyntheticPairedData(shp, nm, sp['validation'], slices_per_volume, data_seed + 101)
+        rng = np.random.RandomState(seed + 7)
+        bs = self.conf.batch_size
+
+        def dev(a):
+            return nn.to_device(a, self.device) if device_resident else a
+
+        def it(arrays):
+            return self.batch_iterator([_Indexable(dev(a)) for a in arrays], bs, rng)
+
+        d = self.data
+        self.gen_labelled = it([d.get_images_modi(0), d.get_images_modi(1), d.get_masks_modi(0), d.get_masks_modi(1)])
+        if self.ul_data is not None:
+            u = self.ul_data
+            self.gen_unlabelled = it([u.get_images_modi(0), u.get_images_modi(1), u.get_masks_modi(0)])
+        all_masks = np.concatenate([d.get_masks_modi(0), d.get_masks_modi(1)], 0)
+        self.discriminator_masks = it([all_masks])
+        imgs = [np.concatenate([d.get_images_modi(m)] + ([self.ul_data.get_images_modi(m)] if self.ul_data else []), 0)
+                for m in range(2)]
+        self.discriminator_image = [it([imgs[0]]), it([imgs[1]])]
+        self.batches = int(np.ceil(d.size() / float(bs)))
+
+    def get_loss_names(self):
+        return ['adv_M', 'adv_X1', 'adv_X2', 'rec_X', 'dis_M', 'dis_X1', 'dis_X2',
+                'val_loss', 'val_loss_mod1', 'val_loss_mod2',
+                'val_loss_mod2_mod1def', 'val_loss_mod1_mod2def', 'val_loss_mod2_fused', 'val_loss_mod1_fused',
+                'val_weight_0', 'val_weight_1', 'val_weight_2',
+                'supervised_Mask', 'KL', 'rec_Z']
+
+    # ---- epoch loop (dafnet_executor.py:212-284) -------------------------------------------------------------------
+    def train(self):
+        log.info('Training Model')
+        self.init_train_data()
+        if not os.path.exists(self.conf.folder):
+            os.makedirs(self.conf.folder)
+        es = EarlyStopping('val_loss_mod2_fused', min_delta=0.01, patience=60)
+        loss_names = self.get_loss_names()
+        total_loss = {n: [] for n in loss_names}
+        csv_path = self.conf.folder + '/training.csv'
+        with open(csv_path, 'w') as f:
+            f.write('epoch,' + ','.join(loss_names) + '\n')
+        for self.epoch in range(self.conf.epochs):
+            log.info('Epoch %d/%d' % (self.epoch, self.conf.epochs))
+            epoch_loss = {n: [] for n in loss_names}
+            for self.batch in range(self.batches):
+                self.train_batch(epoch_loss)
+            self.validate(epoch_loss)
+            for n in loss_names:
+                total_loss[n].append(np.mean([_f(v) for v in epoch_loss[n]]) if epoch_loss[n] else float('nan'))
+            logs = {l: total_loss[l][-1] for l in loss_names}
+            log.info(str('Epoch %d/%d: ' + ', '.join([l + ' Loss = %.5f' for l in loss_names])) %
+                     ((self.epoch, self.conf.epochs) + tuple(total_loss[l][-1] for l in loss_names)))
+            with open(csv_path, 'a') as f:
+                f.write('%d,' % self.epoch + ','.join('%.6f' % logs[l] for l in loss_names) + '\n')
+            self.model.save_models()
+            if self.stop_criterion(es, logs):
+                log.info('Finished training from early stopping criterion')
+                break
+        return total_loss
+
+    def test(self):
+        """Per-volume Dice on the synthetic test split for the 'simple' / 'def' / 'max' fusion modes
+        (reference model_tester.py:30-85)."""
+        sp = synthetic.splits()
+        data = synthetic.SyntheticPairedData(self.conf.input_shape, self.conf.num_masks, sp['test'], 20, 1234 + 202)
+        rows = []
+        for vol in data.volumes():
+            x1, _ = data.get_volume(0, vol)
+            x2, m2 = data.get_volume(1, vol)
+            for t in ('simple', 'def', 'max'):
+                pred = self.model.predict_mask(1, t, [x1, x2])
+                rows.append((vol, t, costs.dice(m2, pred, binarise=True)))
+        if not os.path.exists(self.conf.folder):
+            os.makedirs(self.conf.folder)
+        with open(self.conf.folder + '/results.csv', 'w') as f:
+            f.write('Vol,Type,Dice\n')
+            for r in rows:
+                f.write('%d,%s,%.6f\n' % r)
+        return rows
+
+    def validate(self, epoch_loss):
+        """1 - Dice on the validation split for each modality / deformed / fused input (dafnet_executor.py:303-355)"""
+        v = self.val_data
+        x1, x2 = v.get_images_modi(0), v.get_images_modi(1)
+        m1, m2 = v.get_masks_modi(0), v.get_masks_modi(1)
+        s1 = self.model.Encoders_Anatomy[0].predict(x1)
+        s2 = self.model.Encoders_Anatomy[1].predict(x2)
+        s1_def, s1_fused = self.model.Anatomy_Fuser.predict([s1, s2])
+        s2_def, s2_fused = self.model.Anatomy_Fuser.predict([s2, s1])
+        seg = self.model.Segmentor.predict
+        l_mod1 = 1 - costs.dice(m1, seg(s1), binarise=True)
+        l_mod2 = 1 - costs.dice(m2, seg(s2), binarise=True)
+        l_mod2_mod1def = 1 - costs.dice(m2, seg(s1_def), binarise=True)
+        l_mod1_mod2def = 1 - costs.dice(m1, seg(s2_def), binarise=True)
+        l_mod2_fused = 1 - costs.dice(m2, seg(s1_fused), binarise=True)
+        l_mod1_fused = 1 - costs.dice(m1, seg(s2_fused), binarise=True)
+        for k, val in (('val_loss_mod1', l_mod1), ('val_loss_mod2', l_mod2), ('val_loss_mod2_mod1def', l_mod2_mod1def),
+                       ('val_loss_mod1_mod2def', l_mod1_mod2def), ('val_loss_mod2_fused', l_mod2_fused),
+                       ('val_loss_mod1_fused', l_mod1_fused)):
+            epoch_loss[k].append(val)
+        epoch_loss['val_loss'].append(np.mean([l_mod1, l_mod2, l_mod2_mod1def, l_mod1_mod2def, l_mod2_fused, l_mod1_fused]))
+
+    # ---- one iteration (dafnet_executor.py:369-387) ----------------------------------------------------------------
+    def train_batch(self, epoch_loss):
+        if self.conf.automatedpairing:
+            raise NotImplementedError('automated pairing (SURVEY 8f rank 4)')
+        if self.conf.l_mix > 0:
+            self.train_supervised_expert_pairing(epoch_loss)
+            self.train_batch_mask_discriminator(epoch_loss)
+            self.train_batch_image_discriminator(epoch_loss)
+        if self.conf.l_mix < 1:
+            self.train_unsupervised_expert_pairing(epoch_loss)
+            self.train_batch_mask_discriminator(epoch_loss)
+            self.train_batch_image_discriminator(epoch_loss)
+
+    def _residual(self, m):
+        """add_residual on whatever side the masks live (base_executor.py:83-87): background = 1 - union"""
+        if isinstance(m, torch.Tensor):
+            return _add_residual_device(m)
+        return self.add_residual(m).astype(np.float32)
+
+    def prepare_data_to_train(self, x1, x2, m1, m2):
+        """dafnet_executor.py:482-500 (n_pairs = 1)"""
+        nm = self.conf.num_masks
+        m1 = self._residual(m1[..., 0:nm])
+        m2 = self._residual(m2[..., 0:nm]) if m2 is not None else None
+        batch_size = x1.shape[0]
+        norm = NormalDistribution()
+        z1 = norm.sample((batch_size, self.conf.num_z)).astype(np.float32)
+        z2 = norm.sample((batch_size, self.conf.num_z)).astype(np.float32)
+        return m1, m2, x1, x2, z1, z2
+
+    def train_supervised_expert_pairing(self, epoch_loss):
+        x1, x2, m1, m2 = next(self.gen_labelled)
+        m1, m2, x1, x2, z1, z2 = self.prepare_data_to_train(x1, x2, m1, m2)
+        h = self.model.supervised_trainer.fit([x1, x2, z1, z2],
+                                              [m1, m2, m1, m2] +      # supervised cost
+                                              [1.0 for _ in range(4)] +  # mask adversarial (ones)
+                                              [x1, x2, x1, x2] +      # reconstruction cost
+                                              [1.0 for _ in range(4)] +  # image adversarial (ones)
+                                              [0.0 for _ in range(2)] +  # KL divergence (zeros; costs.ypred ignores it)
+                                              [z1, z2])
+        self.store_training_losses(h, epoch_loss)
+
+    def train_unsupervised_expert_pairing(self, epoch_loss):
+        x1, x2, m1 = next(self.gen_unlabelled)
+        m1, _, x1, x2, z1, z2 = self.prepare_data_to_train(x1, x2, m1, None)
+        h = self.model.unsupervised_trainer.fit([x1, x2, z1, z2],
+                                                [m1, m1] + [1.0 for _ in range(4)] + [x1, x2, x1, x2] +
+                                                [1.0 for _ in range(4)] + [0.0 for _ in range(2)] + [z1, z2])
+        self.store_training_losses(h, epoch_loss)
+
+    def store_training_losses(self, h, epoch_loss):
+        """dafnet_executor.py:502-509 (keras keeps the LAST output's loss under a duplicated name)"""
+        hist = h.history
+        g = (lambda k: hist._dev[k]) if self.keep_losses_on_device else (lambda k: hist[k][0])
+        epoch_loss['supervised_Mask'].append(g('Segmentor_loss'))
+        epoch_loss['adv_M'].append(g('D_Mask_loss'))
+        epoch_loss['rec_X'].append(g('Decoder_loss'))
+        epoch_loss['adv_X1'].append(g('D_Image1_loss'))
+        epoch_loss['adv_X2'].append(g('D_Image2_loss'))
+        epoch_loss['KL'].append(g('Enc_Modality_loss'))
+        epoch_loss['rec_Z'].append(g('ZReconstruct_loss'))
+
+    # ---- fake pools, generated in `predict` mode and kept on the device ---------------------------------------------
+    def mask_pools(self, x1, x2):
+        """dafnet_executor.py:524-543 -> (pool of 2B fake masks for modality 1, same for modality 2)"""
+        m, nm = self.model, self.conf.num_masks
+        fake_s1 = m.Encoders_Anatomy[0].predict(x1)
+        fake_s2 = m.Encoders_Anatomy[1].predict(x2)
+        fake_m1 = m.Segmentor.predict(fake_s1)
+        s2_def, _ = m.Anatomy_Fuser.predict([fake_s2, fake_s1])
+        fake_m1_from_s2 = m.Segmentor.predict(s2_def)
+        pool1 = torch.cat([fake_m1[..., 0:nm], fake_m1_from_s2[..., 0:nm]], 0).contiguous()
+        fake_m2 = m.Segmentor.predict(fake_s2)
+        s1_def, _ = m.Anatomy_Fuser.predict([fake_s1, fake_s2])
+        fake_m2_from_s1 = m.Segmentor.predict(s1_def)
+        pool2 = torch.cat([fake_m2[..., 0:nm], fake_m2_from_s1[..., 0:nm]], 0).contiguous()
+        return pool1, pool2
+
+    def image_pools(self, x1, x2, eps1=None, eps2=None):
+        """dafnet_executor.py:555-575 -> (pool of 3B fake images for modality 1, same for modality 2)"""
+        m = self.model
+        s1 = m.Encoders_Anatomy[0].predict(x1)
+        s2 = m.Encoders_Anatomy[1].predict(x2)
+        s1_def = m.Anatomy_Fuser.predict([s1, s2])[0]
+        s2_def = m.Anatomy_Fuser.predict([s2, s1])[0]
+        z1, _ = m.Enc_Modality.predict([s1, x1], eps=eps1)
+        z2, _ = m.Enc_Modality.predict([s2, x2], eps=eps2)
+        dec = m.Decoder.predict
+        y1 = torch.cat([dec([s1, z1]), dec([s2_def, z1]), dec([s1_def, z1])], 0)
+        y2 = torch.cat([dec([s2, z2]), dec([s1_def, z2]), dec([s2_def, z2])], 0)
+        return y1, y2
+
+    def _sample(self, pool, batch_size):
+        """utils.data_utils.sample: np.random.choice(len, size, replace=False), gathered on the device"""
+        idx = data_utils.sample_indices(pool.shape[0], batch_size)
+        return pool.index_select(0, torch.as_tensor(idx, dtype=torch.long, device=pool.device))
+
+    def train_batch_mask_discriminator(self, epoch_loss):
+        """dafnet_executor.py:511-545"""
+        nm = self.conf.num_masks
+        m1 = _dev(next(self.discriminator_masks), self.device)[..., 0:nm]
+        m2 = _dev(next(self.discriminator_masks), self.device)[..., 0:nm]
+        x1, x2 = [_dev(next(gen), self.device) for gen in self.discriminator_image]
+        mn = min(x1.shape[0], x2.shape[0], m1.shape[0], m2.shape[0])
+        x1, x2, m1, m2 = x1[:mn], x2[:mn], m1[:mn].contiguous(), m2[:mn].contiguous()
+        pool1, pool2 = self.mask_pools(x1, x2)
+        h = self.model.D_Mask_trainer.fit([m1, self._sample(pool1, mn)], [1.0, 0.0])
+        epoch_loss['dis_M'].append(self._loss(h, 'loss'))
+        h = self.model.D_Mask_trainer.fit([m2, self._sample(pool2, mn)], [1.0, 0.0])
+        epoch_loss['dis_M'].append(self._loss(h, 'loss'))
+
+    def train_batch_image_discriminator(self, epoch_loss):
+        """dafnet_executor.py:547-583"""
+        x1, x2 = [_dev(next(gen), self.device) for gen in self.discriminator_image]
+        mn = min(x1.shape[0], x2.shape[0])
+        x1, x2 = x1[:mn], x2[:mn]
+        y1, y2 = self.image_pools(x1, x2)
+        y1 = self._sample(y1, mn)
+        y2 = self._sample(y2, mn)
+        h = self.model.D_Image1_trainer.fit([x1, y1], [1.0, 0.0])
+        epoch_loss['dis_X1'].append(self._loss(h, 'loss'))
+        h = self.model.D_Image2_trainer.fit([x2, y2], [1.0, 0.0])
+        epoch_loss['dis_X2'].append(self._loss(h, 'loss'))
+
+    def _loss(self, h, key):
+        return h.history._dev[key] if self.keep_losses_on_device else h.history[key][0]
+
+
+class _Indexable(object):
+    """array or device tensor with numpy-index-array batching"""
+
+    def __init__(self, a):
+        self.a = a
+        self.shape = a.shape
+
+    def __getitem__(self, idx):
+        if isinstance(self.a, torch.Tensor):
+            return self.a.index_select(0, torch.as_tensor(idx, dtype=torch.long, device=self.a.device))
+        return self.a[idx]
+
+
+def _dev(x, device):
+    return nn.to_device(x, device)
+
+
+def _add_residual_device(m):
+    """background = 1 where no mask is set (masks are {0,1} floats) -- pure data preparation on the device"""
+    res = (m.sum(-1, keepdim=True) < 0.5).to(m.dtype)
+    return torch.cat([m, res], -1).contiguous()
+
+
+def _f(v):
+    return float(v.item()) if hasattr(v, 'item') else float(v)

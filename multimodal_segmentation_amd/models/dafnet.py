@@ -1,0 +1,180 @@
+"""DAFNet: model wrapper wiring the components into the compiled trainers (reference models/dafnet.py).
+
+Generator trainers (get_params_expert_pairing, dafnet.py:163-222): inputs [x1, x2, z1_input, z2_input]; 20 outputs
+(supervised) / 18 (unsupervised: no m2, no m2_s1_def) with the loss table of build_trainers_expertpairs
+(dafnet.py:145-149): Segmentor -> combined Dice + 0.01*BCE (w_sup_M), D_Mask -> mse (w_adv_M), Decoder -> mae
+(w_rec_X), D_Image1/2 -> mse (w_adv_X), Enc_Modality -> ypred on the KL output (w_kl), ZReconstruct -> mae (w_rec_Z).
+supervised_trainer and unsupervised_trainer share the generator weights but own separate Adam states
+(dafnet.py:155,161).  The three discriminators are frozen inside the generator trainers (make_trainable(...,
+False), dafnet.py:119-121) and trained by their own trainers (dafnet.py:75-115, mmsdnet.py:62-77).
+"""
+import logging
+import os
+import traceback
+
+from .. import costs, nn, ops
+from ..model_components import anatomy_fuser, modality_encoder, segmentor, decoder, balancer
+from ..model_components.anatomy_encoder import AnatomyEncoders
+from .discriminator import Discriminator
+from .mmsdnet import MMSDNet, _MuView, _Frozen
+from .trainer import Trainer, OutputSpec
+
+log = logging.getLogger('dafnet')
+
+
+class DAFNet(MMSDNet):
+    def __init__(self, conf):
+        super(DAFNet, self).__init__(conf)
+        self.D_Image1 = None
+        self.D_Image2 = None
+        self.Balancer = None
+        self.D_Image1_trainer = None
+        self.D_Image2_trainer = None
+
+    def build(self):
+        self.build_mask_discriminator()
+        self.build_image_discriminator1()
+        self.build_image_discriminator2()
+        self.build_generators()
+        try:
+            self.load_models()
+        except Exception:
+            log.warning('No models found')
+            traceback.print_exc()
+
+    # ---- checkpoint layout <folder>/models/<component> (dafnet.py:54-73) ----------------------------------------------
+    def _checkpoint_items(self):
+        return [('D_Mask', self.D_Mask), ('D_Image1', self.D_Image1), ('D_Image2', self.D_Image2),
+                ('Enc_Anatomy1', self.Encoders_Anatomy[0]), ('Enc_Anatomy2', self.Encoders_Anatomy[1]),
+                ('Enc_Modality', self.Enc_Modality), ('Anatomy_Fuser', self.Anatomy_Fuser), ('Segmentor', self.Segmentor),
+                ('Decoder', self.Decoder)]
+
+    def load_models(self):
+        model_folder = self.conf.folder + '/models/'
+        if not os.path.exists(model_folder + 'D_Mask'):
+            return
+        log.info('Loading trained models from file')
+        for fname, m in self._checkpoint_items():
+            m.load_weights(model_folder + fname)
+        try:
+            self.Balancer.load_weights(model_folder + 'Balancer')
+        except Exception:
+            pass
+
+    def save_models(self, postfix=''):
+        model_folder = self.conf.folder + '/models/'
+        if not os.path.exists(model_folder):
+            os.makedirs(model_folder)
+        for fname, m in self._checkpoint_items():
+            m.save_weights(model_folder + fname + postfix)
+        if self.Balancer is not None:
+            self.Balancer.save_weights(model_folder + 'Balancer' + postfix)
+
+    # ---- discriminators ---------------------------------------------------------------------------------------------
+    def _build_image_discriminator(self, name):
+        params = self.conf.d_image_params
+        params['name'] = name
+        D = Discriminator(params)
+        D.build()
+        log.info('Image Discriminator ' + name)
+        return D.model, self._d_trainer(D.model, name + '_trainer', self.conf.d_image_params.lr)
+
+    def build_image_discriminator1(self):
+        self.D_Image1, self.D_Image1_trainer = self._build_image_discriminator('D_Image1')
+
+    def build_image_discriminator2(self):
+        self.D_Image2, self.D_Image2_trainer = self._build_image_discriminator('D_Image2')
+
+    # ---- generators -----------------------------------------------------------------------------------------------
+    def build_generators(self):
+        assert self.D_Mask is not None, 'Discriminator has not been built yet'
+        self.Encoders_Anatomy = AnatomyEncoders(self.modalities).build(self.conf.anatomy_encoder)
+        self.Anatomy_Fuser = anatomy_fuser.build(self.conf)
+        self.Enc_Modality = modality_encoder.build(self.conf)
+        self.Enc_Modality_mu = _MuView(self.Enc_Modality)
+        self.Segmentor = segmentor.build(self.conf)
+        self.Decoder = decoder.build(self.conf)
+        self.Balancer = balancer.build(self.conf)
+        self.build_trainers()
+
+    def build_trainers(self):
+        self.build_z_regressor()
+        if not self.conf.automatedpairing:
+            self.build_trainers_expertpairs()
+        else:
+            raise NotImplementedError('automated pairing graph (dafnet.py:224-334) is a "next" row (SURVEY 8f rank 4)')
+
+    def build_z_regressor(self):
+        self.Z_Regressor = self._z_regressor(2)       # dafnet.py:336-350
+
+    def _expert_graph(self, supervised):
+        """get_params_expert_pairing (dafnet.py:163-222)"""
+        nm = self.conf.num_masks
+
+        def graph(ins, training=True, eps=None, teacher_s=None):
+            x1, x2, z1_input, z2_input = ins
+            eps = eps or [None, None]
+            with _Frozen([self.D_Mask, self.D_Image1, self.D_Image2]):
+                # encode
+                s1 = self.Encoders_Anatomy[0](x1, training=training)
+                s2 = self.Encoders_Anatomy[1](x2, training=training)
+                if teacher_s is not None:           # parity harness: force the oracle's rounded anatomies
+                    s1 = ops.ste_replace(s1, teacher_s[0])
+                    s2 = ops.ste_replace(s2, teacher_s[1])
+                z1, kl1 = self.Enc_Modality(s1, x1, eps=eps[0])
+                z2, kl2 = self.Enc_Modality(s2, x2, eps=eps[1])
+                # segment
+                m1 = self.Segmentor(s1, training=training)
+                m2 = self.Segmentor(s2, training=training)
+                # decoder
+                y1 = self.Decoder(s1, z1)
+                y2 = self.Decoder(s2, z2)
+                # GANs
+                adv_m = lambda m: self.D_Mask(ops.slice_channels(m, 0, nm))
+                adv_m1, adv_m2 = adv_m(m1), adv_m(m2)
+                adv_y1 = self.D_Image1(y1)
+                adv_y2 = self.D_Image2(y2)
+                # deform and fuse
+                s1_def, _ = self.Anatomy_Fuser(s1, s2)
+                s2_def, _ = self.Anatomy_Fuser(s2, s1)
+                # segment
+                m2_s1_def = self.Segmentor(s1_def, training=training)
+                m1_s2_def = self.Segmentor(s2_def, training=training)
+                # decoder (cross-reconstruction)
+                y2_s1_def = self.Decoder(s1_def, z2)
+                y1_s2_def = self.Decoder(s2_def, z1)
+                # GANs
+                adv_m2_s1_def, adv_m1_s2_def = adv_m(m2_s1_def), adv_m(m1_s2_def)
+                adv_y2_s1_def = self.D_Image2(y2_s1_def)
+                adv_y1_s2_def = self.D_Image1(y1_s2_def)
+                # Z-Regressor: Decoder then Enc_Modality_mu (dafnet.py:336-350)
+                z1_rec = self.Enc_Modality(s1, self.Decoder(s1, z1_input), mu_only=True)
+                z2_rec = self.Enc_Modality(s2, self.Decoder(s2, z2_input), mu_only=True)
+            all_outputs = [m1, m2, m1_s2_def, m2_s1_def] if supervised else [m1, m1_s2_def]
+            all_outputs += [adv_m1, adv_m2, adv_m1_s2_def, adv_m2_s1_def] + \
+                           [y1, y2, y1_s2_def, y2_s1_def] + \
+                           [adv_y1, adv_y2, adv_y1_s2_def, adv_y2_s1_def] + \
+                           [kl1, kl2, z1_rec, z2_rec]
+            self.last_factors = {'s1': s1, 's2': s2, 's1_def': s1_def, 's2_def': s2_def, 'z1': z1, 'z2': z2}
+            return all_outputs
+        return graph
+
+    def _expert_specs(self, supervised):
+        c = self.conf
+        seg = costs.make_combined_dice_bce(self.num_masks)
+        n_seg = 4 if supervised else 2
+        return [OutputSpec('Segmentor', seg, c.w_sup_M) for _ in range(n_seg)] + \
+               [OutputSpec('D_Mask', 'mse', c.w_adv_M) for _ in range(4)] + \
+               [OutputSpec('Decoder', 'mae', c.w_rec_X) for _ in range(4)] + \
+               [OutputSpec(n, 'mse', c.w_adv_X) for n in ('D_Image1', 'D_Image2', 'D_Image1', 'D_Image2')] + \
+               [OutputSpec('Enc_Modality', costs.ypred, c.w_kl) for _ in range(2)] + \
+               [OutputSpec('ZReconstruct', 'mae', c.w_rec_Z) for _ in range(2)]
+
+    def build_trainers_expertpairs(self):
+        """Two compiled models over the SAME generator weights, each with its own Adam (dafnet.py:140-161)."""
+        gens = self._generator_models()
+        frozen = [self.D_Mask, self.D_Image1, self.D_Image2]
+        self.unsupervised_trainer = Trainer('unsupervised_trainer', self._expert_graph(False), self._expert_specs(False),
+                                            gens, nn.Adam(self.conf.lr), self.num_masks, regularised=frozen)
+        self.supervised_trainer = Trainer('supervised_trainer', self._expert_graph(True), self._expert_specs(True),
+                                          gens, nn.Adam(self.conf.lr), self.num_masks, regularised=frozen)

@@ -1,0 +1,349 @@
+"""Minimal Keras-shaped model layer for the DAFNet/MMSDNet engine.
+
+What the reference's callers touch of `keras.Model` is mirrored here: calling a model on tensors,
+`.predict`, `.get_weights/.set_weights`, `.save_weights/.load_weights`, `.summary`, `.name`, `.trainable`,
+`.layers`, `.get_layer`, `.input_shape/.output_shape`.  Everything is define-by-run on device tensors.
+
+Memory layout (HBM): every Model keeps its trainable weights in ONE flat fp32 arena (`model.arena`), its
+gradients in a second arena of the same layout (`model.grad_arena`) and its non-trainable state (BatchNorm moving
+statistics, the spectral regulariser's u0) in a third.  Parameter tensors are 16-byte aligned views.  The Adam
+kernel and the data-parallel all-reduce therefore work on whole arenas (one launch / one collective per model).
+Weights are NOT autograd leaves: the autograd tape only carries activation gradients, and the kernels accumulate
+weight gradients straight into the gradient arena.
+"""
+import math
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+
+_DEVICE = None
+
+
+def default_device():
+    global _DEVICE
+    if _DEVICE is None:
+        if torch.cuda.is_available():
+            _DEVICE = torch.device('cuda', torch.cuda.current_device())
+        else:
+            _DEVICE = torch.device('cpu')   # only reachable under the test stand-in; kernels refuse CPU tensors
+    return _DEVICE
+
+
+def set_default_device(dev):
+    global _DEVICE
+    _DEVICE = torch.device(dev)
+
+
+_anchors = {}
+
+
+def anchor(device):
+    """A 1-element tensor that requires grad: fed to every node with trainable weights so that autograd visits
+    the node even when none of its activations requires grad (first layer of a network)."""
+    a = _anchors.get(device)
+    if a is None:
+        a = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)
+        _anchors[device] = a
+    return a
+
+
+# ---- initialisers (Keras 2.1.6 defaults: he_normal/glorot_normal are truncated normals) -----------------------
+def _fans(shape):
+    if len(shape) == 2:
+        return shape[0], shape[1]
+    rf = int(np.prod(shape[:-2]))
+    return shape[-2] * rf, shape[-1] * rf
+
+
+def _trunc_normal(rng, shape, std):
+    out = rng.standard_normal(size=shape)
+    bad = np.abs(out) > 2
+    while bad.any():
+        out[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(out) > 2
+    return out * std
+
+
+def initialise(rng, shape, kind):
+    if kind == 'zeros':
+        return np.zeros(shape, np.float32)
+    if kind == 'ones':
+        return np.ones(shape, np.float32)
+    if kind == 'uniform_pm1':      # Spectral.u (layers/spectralnorm.py:213 of the reference)
+        return (rng.random_sample(shape) * 2 - 1.).astype(np.float32)
+    fi, fo = _fans(shape)
+    if kind == 'he_normal':
+        return _trunc_normal(rng, shape, math.sqrt(2.0 / fi)).astype(np.float32)
+    if kind == 'glorot_normal':
+        return _trunc_normal(rng, shape, math.sqrt(2.0 / (fi + fo))).astype(np.float32)
+    if kind == 'glorot_uniform':
+        lim = math.sqrt(6.0 / (fi + fo))
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+    raise ValueError(kind)
+
+
+class Param(object):
+    __slots__ = ('name', 'shape', 'init', 'trainable', 'data', 'grad', 'owner', 'offset')
+
+    def __init__(self, name, shape, init, trainable=True):
+        self.name, self.shape, self.init, self.trainable = name, tuple(shape), init, trainable
+        self.data = self.grad = self.owner = None
+        self.offset = 0
+
+    @property
+    def numel(self):
+        return int(np.prod(self.shape))
+
+    def g(self):
+        """Gradient view to accumulate into, or None when the owning model is frozen / not recording."""
+        return self.grad if (self.trainable and self.owner.trainable and torch.is_grad_enabled()) else None
+
+
+class Model(object):
+    """A named component with parameters.  Sub-classes declare parameters in __init__ via add_param (Keras weight
+    order = declaration order), call finalize(), and implement forward(*tensors, training=...)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.trainable = True
+        self.params = OrderedDict()
+        self.arena = self.grad_arena = self.state_arena = None
+        self.input_shape = self.output_shape = None
+        self.shared = []           # other Models whose weights are part of this one (shared layers)
+
+    # ---- construction --------------------------------------------------------------------------------------
+    def add_param(self, name, shape, init, trainable=True):
+        p = Param(name, shape, init, trainable)
+        p.owner = self
+        self.params[name] = p
+        return p
+
+    def finalize(self, rng, device=None):
+        device = device or default_device()
+        off_t = off_s = 0
+        for p in self.params.values():
+            n = (p.numel + 3) // 4 * 4     # 16-byte aligned views
+            if p.trainable:
+                p.offset, off_t = off_t, off_t + n
+            else:
+                p.offset, off_s = off_s, off_s + n
+        host_t = np.zeros(max(off_t, 4), np.float32)
+        host_s = np.zeros(max(off_s, 4), np.float32)
+        for p in self.params.values():
+            v = initialise(rng, p.shape, p.init).reshape(-1)
+            (host_t if p.trainable else host_s)[p.offset:p.offset + p.numel] = v
+        self.arena = torch.from_numpy(host_t).to(device)
+        self.state_arena = torch.from_numpy(host_s).to(device)
+        self.grad_arena = torch.empty_like(self.arena)
+        ops.fill_(self.grad_arena, 0.0)
+        for p in self.params.values():
+            if p.trainable:
+                p.data = self.arena[p.offset:p.offset + p.numel].view(p.shape)
+                p.grad = self.grad_arena[p.offset:p.offset + p.numel].view(p.shape)
+            else:
+                p.data = self.state_arena[p.offset:p.offset + p.numel].view(p.shape)
+        self.device = device
+        return self
+
+    # ---- keras.Model surface -------------------------------------------------------------------------------
+    @property
+    def layers(self):
+        seen, out = set(), []
+        for n in self.params:
+            l = n.split('/')[0]
+            if l not in seen:
+                seen.add(l)
+                out.append(l)
+        return out
+
+    def get_layer(self, name):
+        ps = OrderedDict((k, v) for k, v in self.params.items() if k.split('/')[0] == name)
+        if not ps:
+            raise ValueError('No such layer: ' + name)
+        return ps
+
+    def all_params(self):
+        ps = list(self.params.values())
+        for m in self.shared:
+            ps += m.all_params()
+        return ps
+
+    def owned_models(self):
+        out = [self]
+        for m in self.shared:
+            out += m.owned_models()
+        return out
+
+    def get_weights(self):
+        return [p.data.detach().cpu().numpy().copy() for p in self.all_params()]
+
+    def set_weights(self, weights):
+        ps = self.all_params()
+        if len(weights) != len(ps):
+            raise ValueError('%s expects %d weight arrays, got %d' % (self.name, len(ps), len(weights)))
+        for p, w in zip(ps, weights):
+            w = np.asarray(w, np.float32)
+            if tuple(w.shape) != p.shape:
+                raise ValueError('weight %s: shape %s != %s' % (p.name, w.shape, p.shape))
+            p.data.copy_(torch.from_numpy(w).to(p.data.device))
+
+    def named_weights(self, prefix=''):
+        """name -> numpy array (the oracle's parameter naming)."""
+        out = OrderedDict()
+        for p in self.params.values():
+            out[prefix + p.name] = p.data.detach().cpu().numpy().copy()
+        return out
+
+    def count_params(self):
+        return sum(p.numel for p in self.all_params())
+
+    def save_weights(self, path):
+        arrs = {('%04d' % i): w for i, w in enumerate(self.get_weights())}
+        with open(path, 'wb') as f:      # same file name as the reference (no extension), npz container
+            np.savez(f, **arrs)
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z[k] for k in sorted(z.files)])
+
+    def summary(self, print_fn=print):
+        print_fn('Model: %s' % self.name)
+        for p in self.all_params():
+            print_fn('  %-40s %-24s %d' % (p.name, str(p.shape), p.numel))
+        print_fn('Total params: %d' % self.count_params())
+
+    def get_output_shape_at(self, idx):
+        return self.output_shape
+
+    # ---- execution -----------------------------------------------------------------------------------------
+    def forward(self, *inputs, **kw):
+        raise NotImplementedError
+
+    def __call__(self, *inputs, **kw):
+        return self.forward(*inputs, **kw)
+
+    def predict(self, inputs, **kw):
+        """keras `predict`: inference mode (moving BN statistics), no tape.  numpy in -> numpy out; device tensors
+        in -> device tensors out (no host round trip)."""
+        single = not isinstance(inputs, (list, tuple))
+        ins = [inputs] if single else list(inputs)
+        as_numpy = not isinstance(ins[0], torch.Tensor)
+        ts = [to_device(x, self.device) for x in ins]
+        with torch.no_grad():
+            out = self.forward(*ts, training=False, **kw)
+        if isinstance(out, (list, tuple)):
+            return [to_numpy(o) for o in out] if as_numpy else list(out)
+        return to_numpy(out) if as_numpy else out
+
+    def zero_grad_own(self):
+        """Zero this model's own gradient arena (shared sub-models are separate entries of a trainer's list)."""
+        ops.fill_(self.grad_arena, 0.0)
+
+    def zero_grad(self):
+        for m in self.owned_models():
+            ops.fill_(m.grad_arena, 0.0)
+
+
+def to_device(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float32)
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+
+
+def to_numpy(t):
+    return t.detach().cpu().numpy()
+
+
+# ---- layer helpers: declare parameters with the oracle's names, apply with the fused kernels -------------------
+def conv_params(m, name, k, cin, cout, init='glorot_uniform', bias=True):
+    m.add_param(name + '/kernel', (k, k, cin, cout), init)
+    if bias:
+        m.add_param(name + '/bias', (cout,), 'zeros')
+
+
+def dense_params(m, name, cin, cout, init='glorot_uniform'):
+    m.add_param(name + '/kernel', (cin, cout), init)
+    m.add_param(name + '/bias', (cout,), 'zeros')
+
+
+def bn_params(m, name, c):
+    m.add_param(name + '/gamma', (c,), 'ones')
+    m.add_param(name + '/beta', (c,), 'zeros')
+    m.add_param(name + '/moving_mean', (c,), 'zeros', trainable=False)
+    m.add_param(name + '/moving_variance', (c,), 'ones', trainable=False)
+
+
+def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False):
+    w = m.params[name + '/kernel']
+    b = m.params.get(name + '/bias')
+    return ops.conv2d(x, w.data, b.data if b is not None else None, stride, padding, act, alpha, x2, upsample,
+                      wgrad=w.g(), bgrad=b.g() if b is not None else None, anchor=anchor(x.device))
+
+
+def dense(m, name, x, act=None, alpha=0.0):
+    w, b = m.params[name + '/kernel'], m.params[name + '/bias']
+    return ops.dense(x, w.data, b.data, act, alpha, wgrad=w.g(), bgrad=b.g(), anchor=anchor(x.device))
+
+
+def bn(m, name, x, training, relu=False):
+    g, b = m.params[name + '/gamma'], m.params[name + '/beta']
+    return ops.batchnorm(x, g.data, b.data, m.params[name + '/moving_mean'].data,
+                         m.params[name + '/moving_variance'].data, training, relu,
+                         ggrad=g.g(), bgrad=b.g(), anchor=anchor(x.device))
+
+
+# ---- Keras 2.1.6 Adam over the arenas of a set of models -------------------------------------------------------
+class Adam(object):
+    """keras.optimizers.Adam(lr): beta (0.9, 0.999), epsilon 1e-7, bias correction folded into lr_t.  One instance
+    per compiled trainer: the reference gives supervised_trainer and unsupervised_trainer separate states over the
+    same weights (models/dafnet.py:155,161)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
+        self.iterations = 0
+        self.state = {}
+
+    def step(self, models):
+        self.iterations += 1
+        t = self.iterations
+        lr_t = self.lr * math.sqrt(1. - self.beta_2 ** t) / (1. - self.beta_1 ** t)
+        for m in models:
+            st = self.state.get(id(m))
+            if st is None:
+                st = (ops.fill_(torch.empty_like(m.arena), 0.0), ops.fill_(torch.empty_like(m.arena), 0.0))
+                self.state[id(m)] = st
+            ops.adam_step(m.arena, m.grad_arena, st[0], st[1], lr_t, self.beta_1, self.beta_2, self.epsilon)
+
+
+class History(object):
+    """keras History: .history[name] is a one-element list.  Values stay on the device until read."""
+
+    def __init__(self):
+        self._dev = OrderedDict()
+
+    def record(self, name, value):
+        self._dev[name] = value      # later duplicates overwrite earlier ones, like Keras' logs dict
+
+    @property
+    def history(self):
+        return _LazyHistory(self._dev)
+
+
+class _LazyHistory(dict):
+    def __init__(self, dev):
+        super(_LazyHistory, self).__init__()
+        self._dev = dev
+
+    def __getitem__(self, k):
+        v = self._dev[k]
+        return [float(v.item()) if hasattr(v, 'item') else float(v)]
+
+    def __contains__(self, k):
+        return k in self._dev
+
+    def keys(self):
+        return self._dev.keys()

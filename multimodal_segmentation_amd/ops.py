@@ -65,9 +65,17 @@ def _conv_fwd_raw(x1, x2, w, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
            ups, transposed, act, float(alpha), nsplit1)
 
 
+def _accumulate(dst, src):
+    """dst += src (weight-gradient accumulation into the gradient arena)."""
+    N.call('mmseg_axpby', dst, src, dst, dst.numel(), 1.0, 1.0)
+
+
 class _Conv2d(torch.autograd.Function):
+    """inputs: activations x1 [, x2], the tape anchor, then non-differentiable arguments.  Weight / bias gradients
+    are accumulated into `wgrad` / `bgrad` (views of the owner's gradient arena) instead of being returned."""
+
     @staticmethod
-    def forward(ctx, x1, x2, w, bias, stride, padding, act, alpha, ups):
+    def forward(ctx, x1, x2, anchor, w, bias, stride, padding, act, alpha, ups, wgrad, bgrad):
         x1 = _c(x1)
         x2 = _c(x2) if x2 is not None else None
         B, H1, W1, C1 = x1.shape
@@ -82,13 +90,15 @@ class _Conv2d(torch.autograd.Function):
         _conv_fwd_raw(x1, x2, w, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,
                       ACT[act], alpha, 0)
         ctx.geom = (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), ACT[act], alpha)
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(x1, x2, w, y if ACT[act] else None)
+        ctx.wgrad, ctx.bgrad = wgrad, bgrad
+        ctx.w = w     # plain (non-leaf) weight view: not tracked by autograd
+        ctx.save_for_backward(x1, x2, y if ACT[act] else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x1, x2, w, y = ctx.saved_tensors
+        x1, x2, y = ctx.saved_tensors
+        w = ctx.w
         B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, act, alpha = ctx.geom
         dy = _c(dy)
         if act:
@@ -96,19 +106,19 @@ class _Conv2d(torch.autograd.Function):
             N.call('mmseg_act_bwd', dy, y, g, dy.numel(), act, float(alpha))
         else:
             g = dy
-        need_x1, need_x2, need_w, need_b = ctx.needs_input_grad[:4]
-        dx1 = dx2 = dw = db = None
+        need_x1, need_x2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx1 = dx2 = None
         M = B * Ho * Wo
-        if ctx.has_bias and need_b:
-            db = _new((Cout,), dy)
+        if ctx.bgrad is not None:
             ws = _ws('colsum', N.call('mmseg_colsum_blocks', M) * Cout, dy.device)
-            N.call('mmseg_colsum', g, db, ws, M, Cout, 1.0, 0)
-        if need_w:
-            dw = _new(w.shape, dy)
+            N.call('mmseg_colsum', g, ctx.bgrad, ws, M, Cout, 1.0, 1)
+        if ctx.wgrad is not None:
+            dw = _ws('dw_tmp', w.numel(), dy.device)[:w.numel()]
             need = N.call('mmseg_conv2d_wgrad_workspace', B, Ho, Wo, C1 + C2, Cout, KH, KW)
             ws = _ws('wgrad', need, dy.device)
             N.call('mmseg_conv2d_wgrad', x1, x2, g, dw, ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride,
                    ph, pw, ups)
+            _accumulate(ctx.wgrad.view(-1), dw)
         if need_x1 or (x2 is not None and need_x2):
             Cin = C1 + C2
             wt = _ws('wflip', w.numel(), dy.device)[:w.numel()]
@@ -124,15 +134,18 @@ class _Conv2d(torch.autograd.Function):
             else:
                 dx1 = d1
             dx2 = d2
-        return dx1, dx2, dw, db, None, None, None, None, None
+        return (dx1, dx2) + (None,) * 10
 
 
-def conv2d(x, w, bias=None, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False):
+def conv2d(x, w, bias=None, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False,
+           wgrad=None, bgrad=None, anchor=None):
     """keras Conv2D on NHWC (+ fused nearest x2 up-sampling of x, + fused channel concat with x2, + fused
-    bias/activation epilogue)."""
+    bias/activation epilogue).  `wgrad`/`bgrad`: gradient-arena views to accumulate into (None = frozen)."""
     if upsample and (x.shape[3] % 4 != 0):
         raise ValueError('fused up-sampling needs C % 4 == 0')
-    return _Conv2d.apply(x, x2, w, bias, stride, padding, act, alpha, bool(upsample))
+    if wgrad is None and bgrad is None:
+        anchor = None
+    return _Conv2d.apply(x, x2, anchor, w, bias, stride, padding, act, alpha, bool(upsample), wgrad, bgrad)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -140,7 +153,7 @@ def conv2d(x, w, bias=None, stride=1, padding='same', act=None, alpha=0.0, x2=No
 # ------------------------------------------------------------------------------------------------------
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, mov_mean, mov_var, relu):
+    def forward(ctx, x, anchor, gamma, beta, mov_mean, mov_var, relu, ggrad, bgrad):
         x = _c(x)
         C = x.shape[-1]
         M = x.numel() // C
@@ -151,28 +164,36 @@ class _BatchNormTrain(torch.autograd.Function):
         y = _new(x.shape, x)
         N.call('mmseg_bn_apply', x, stats[2], stats[3], y, M, C, int(relu))
         ctx.relu = bool(relu)
-        ctx.save_for_backward(x, y if relu else None, gamma, stats)
+        ctx.gamma, ctx.ggrad, ctx.bgrad = gamma, ggrad, bgrad
+        ctx.save_for_backward(x, y if relu else None, stats)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, stats = ctx.saved_tensors
+        x, y, stats = ctx.saved_tensors
         dy = _c(dy)
         C = x.shape[-1]
         M = x.numel() // C
         dx = _new(x.shape, x)
-        dgamma, dbeta = _new((C,), x), _new((C,), x)
+        tmp = _ws('bn_dgb', 2 * C, x.device)
+        dgamma, dbeta = tmp[:C], tmp[C:2 * C]
         coef = _ws('bn_coef', 3 * C, x.device)
         ws = _ws('norm', N.call('mmseg_norm_workspace_floats', C), x.device)
-        N.call('mmseg_bn_bwd', dy, y, x, gamma, stats[0], stats[1], dx, dgamma, dbeta, coef, ws, M, C, int(ctx.relu))
-        return dx, dgamma, dbeta, None, None, None
+        N.call('mmseg_bn_bwd', dy, y, x, ctx.gamma, stats[0], stats[1], dx, dgamma, dbeta, coef, ws, M, C, int(ctx.relu))
+        if ctx.ggrad is not None:
+            _accumulate(ctx.ggrad, dgamma)
+        if ctx.bgrad is not None:
+            _accumulate(ctx.bgrad, dbeta)
+        return (dx,) + (None,) * 8
 
 
-def batchnorm(x, gamma, beta, mov_mean, mov_var, training, relu=False):
+def batchnorm(x, gamma, beta, mov_mean, mov_var, training, relu=False, ggrad=None, bgrad=None, anchor=None):
     """keras BatchNormalization(axis=-1) [+ ReLU].  training: batch statistics and in-place moving-average update
     (what `fit` does); otherwise the moving statistics (what `predict` does)."""
     if training:
-        return _BatchNormTrain.apply(x, gamma, beta, mov_mean, mov_var, relu)
+        if ggrad is None and bgrad is None:
+            anchor = None
+        return _BatchNormTrain.apply(x, anchor, gamma, beta, mov_mean, mov_var, relu, ggrad, bgrad)
     x = _c(x)
     C = x.shape[-1]
     M = x.numel() // C
@@ -207,6 +228,58 @@ class _MaxPool2(torch.autograd.Function):
 
 def maxpool2(x):
     return _MaxPool2.apply(x)
+
+
+class _Upsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, H, W, C = x.shape
+        y = _new((B, 2 * H, 2 * W, C), x)
+        N.call('mmseg_upsample2_fwd', x, y, B, H, W, C)
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.shape
+        dx = _new(ctx.shape, dy)
+        N.call('mmseg_upsample2_bwd', _c(dy), dx, B, H, W, C)
+        return dx
+
+
+def upsample2(x):
+    """keras UpSampling2D(size=2) (nearest)."""
+    return _Upsample2.apply(x)
+
+
+class _Subsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f):
+        x = _c(x)
+        B, H, W, C = x.shape
+        assert H % f == 0 and W % f == 0
+        y = _new((B, H // f, W // f, C), x)
+        N.call('mmseg_subsample_fwd', x, y, B, H // f, W // f, C, f)
+        ctx.meta = (B, H, W, C, f)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C, f = ctx.meta
+        dx = _new((B, H, W, C), dy)
+        N.call('mmseg_subsample_bwd', _c(dy), dx, B, H // f, W // f, C, f)
+        return dx, None
+
+
+def resize_nearest_down(x, Ho, Wo):
+    """tf.image.resize_nearest_neighbor(x, [Ho, Wo]) for integer down-sampling factors (src = dst * f)."""
+    B, H, W, C = x.shape
+    if (H, W) == (Ho, Wo):
+        return x
+    if H % Ho or W % Wo or H // Ho != W // Wo:
+        raise NotImplementedError('nearest resize: only integer down-sampling factors (%dx%d -> %dx%d)' % (H, W, Ho, Wo))
+    return _Subsample.apply(x, H // Ho)
 
 
 class _SoftmaxRound(torch.autograd.Function):
@@ -253,7 +326,7 @@ def softmax_round(x):
 # ------------------------------------------------------------------------------------------------------
 class _Dense(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, act, alpha):
+    def forward(ctx, x, anchor, w, bias, act, alpha, wgrad, bgrad):
         x = _c(x)
         R, K = x.shape
         K2, Nn = w.shape
@@ -261,13 +334,15 @@ class _Dense(torch.autograd.Function):
         y = _new((R, Nn), x)
         ws = _ws('dense', N.call('mmseg_dense_workspace_floats', R, K, Nn), x.device)
         N.call('mmseg_dense_fwd', x, w, bias, y, ws, R, K, Nn, ACT[act], float(alpha))
-        ctx.act, ctx.alpha, ctx.has_bias = ACT[act], alpha, bias is not None
-        ctx.save_for_backward(x, w, y if ACT[act] else None)
+        ctx.act, ctx.alpha = ACT[act], alpha
+        ctx.w, ctx.wgrad, ctx.bgrad = w, wgrad, bgrad
+        ctx.save_for_backward(x, y if ACT[act] else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, y = ctx.saved_tensors
+        w = ctx.w
         R, K = x.shape
         Nn = w.shape[1]
         dy = _c(dy)
@@ -276,22 +351,24 @@ class _Dense(torch.autograd.Function):
             N.call('mmseg_act_bwd', dy, y, g, dy.numel(), ctx.act, float(ctx.alpha))
         else:
             g = dy
-        dx = dw = db = None
+        dx = None
         if ctx.needs_input_grad[0]:
             dx = _new(x.shape, x)
             N.call('mmseg_dense_dgrad', g, w, dx, R, K, Nn)
-        if ctx.needs_input_grad[1]:
-            dw = _new(w.shape, x)
+        if ctx.wgrad is not None:
+            dw = _ws('dw_tmp', w.numel(), x.device)[:w.numel()]
             N.call('mmseg_dense_wgrad', x, g, dw, R, K, Nn)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _new((Nn,), x)
+            _accumulate(ctx.wgrad.view(-1), dw)
+        if ctx.bgrad is not None:
             ws = _ws('colsum', N.call('mmseg_colsum_blocks', R) * Nn, x.device)
-            N.call('mmseg_colsum', g, db, ws, R, Nn, 1.0, 0)
-        return dx, dw, db, None, None
+            N.call('mmseg_colsum', g, ctx.bgrad, ws, R, Nn, 1.0, 1)
+        return (dx,) + (None,) * 7
 
 
-def dense(x, w, bias=None, act=None, alpha=0.0):
-    return _Dense.apply(x, w, bias, act, alpha)
+def dense(x, w, bias=None, act=None, alpha=0.0, wgrad=None, bgrad=None, anchor=None):
+    if wgrad is None and bgrad is None:
+        anchor = None
+    return _Dense.apply(x, anchor, w, bias, act, alpha, wgrad, bgrad)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -571,3 +648,20 @@ def axpby(a, b, sa=1.0, sb=1.0, out=None):
     out = _new(a.shape, a) if out is None else out
     N.call('mmseg_axpby', _c(a), _c(b), out, a.numel(), float(sa), float(sb))
     return out
+
+
+class _SteReplace(torch.autograd.Function):
+    """Parity harness only: replace a rounded anatomy by a given tensor (teacher forcing across the Rounding
+    discontinuity) while passing the gradient straight through.  No arithmetic."""
+
+    @staticmethod
+    def forward(ctx, s, teacher):
+        return teacher.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def ste_replace(s, teacher):
+    return _SteReplace.apply(s, teacher)

@@ -111,6 +111,7 @@ class DAFNetOracle(object):
     def _step(self, adam_key, names, loss):
         P = self.P
         grads = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
+        self.last_grads = dict(zip(names, grads))
         self.adam[adam_key].step(P, dict(zip(names, grads)))
 
     def _with_grad(self, names):

@@ -128,6 +128,20 @@ def upsample2_bwd(dy, dx, B, H, W, C):
     dx.copy_(d); return 0
 
 
+def upsample2_fwd(x, y, B, H, W, C):
+    y.copy_(O.upsample2(x.reshape(B, H, W, C))); return 0
+
+
+def subsample_fwd(x, y, B, Ho, Wo, C, f):
+    y.copy_(x.reshape(B, Ho * f, Wo * f, C)[:, ::f, ::f]); return 0
+
+
+def subsample_bwd(dy, dx, B, Ho, Wo, C, f):
+    d = torch.zeros(B, Ho * f, Wo * f, C, dtype=dy.dtype)
+    d[:, ::f, ::f] = dy.reshape(B, Ho, Wo, C)
+    dx.copy_(d); return 0
+
+
 def softmax_fwd(x, p, s, npix, C):
     q = torch.softmax(x.reshape(npix, C), -1)
     p.copy_(q.reshape(p.shape))
@@ -291,7 +305,7 @@ def dense_dgrad(dy, w, dx, R, K, N):
 
 
 def dense_wgrad(x, dy, dw, R, K, N):
-    dw.copy_(x.reshape(R, K).t() @ dy.reshape(R, N)); return 0
+    dw.copy_((x.reshape(R, K).t() @ dy.reshape(R, N)).reshape(dw.shape)); return 0
 
 
 def tps_workspace_floats(B):

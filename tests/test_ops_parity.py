@@ -28,11 +28,19 @@ def _close(a, b, name, rtol=RTOL):
     assert err <= rtol * scale + 1e-7, '%s: max err %.3e (scale %.3e)' % (name, err, scale)
 
 
-def check(f_prod, f_ref, inputs, device, grad_mask=None, rtol=RTOL):
+def check(f_prod, f_ref, inputs, device, grad_mask=None, rtol=RTOL, param_idx=()):
     """inputs: list of CPU fp32 tensors.  Runs both functions, a random cotangent, and compares outputs and the
-    gradients of every input with grad_mask[i] true."""
+    gradients of every input with grad_mask[i] true.  Inputs listed in `param_idx` are weights: the product gets
+    them as plain tensors plus a zeroed gradient buffer `t.gbuf` it accumulates into (no autograd leaf)."""
     grad_mask = grad_mask or [True] * len(inputs)
-    xs_p = [t.clone().to(device).requires_grad_(m) for t, m in zip(inputs, grad_mask)]
+    xs_p = []
+    for i, (t, m) in enumerate(zip(inputs, grad_mask)):
+        tp = t.clone().to(device)
+        if i in param_idx:
+            tp.gbuf = torch.zeros_like(tp)
+        else:
+            tp.requires_grad_(m)
+        xs_p.append(tp)
     xs_r = [t.clone().double().requires_grad_(m) for t, m in zip(inputs, grad_mask)]
     yp = f_prod(*xs_p)
     yr = f_ref(*xs_r)
@@ -49,8 +57,13 @@ def check(f_prod, f_ref, inputs, device, grad_mask=None, rtol=RTOL):
     torch.autograd.backward(list(yr), [c.double() for c in cots])
     for i, m in enumerate(grad_mask):
         if m:
-            assert xs_p[i].grad is not None, 'no grad for input %d' % i
-            _close(xs_p[i].grad, xs_r[i].grad, 'grad%d' % i, rtol)
+            gp = xs_p[i].gbuf if i in param_idx else xs_p[i].grad
+            assert gp is not None, 'no grad for input %d' % i
+            _close(gp, xs_r[i].grad, 'grad%d' % i, rtol)
+
+
+def _anchor(t):
+    return torch.zeros(1, device=t.device, requires_grad=True)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -104,7 +117,8 @@ def test_conv2d(case, device):
     inputs = [x1, w, b] + ([rnd(B, H, W, C2, seed=4)] if C2 else [])
 
     def f_prod(x1, w, b, x2=None):
-        return P.conv2d(x1, w, b, stride=stride, padding=padding, act=act, alpha=alpha, x2=x2, upsample=ups)
+        return P.conv2d(x1, w, b, stride=stride, padding=padding, act=act, alpha=alpha, x2=x2, upsample=ups,
+                        wgrad=w.gbuf, bgrad=b.gbuf, anchor=_anchor(x1))
 
     def f_ref(x1, w, b, x2=None):
         xin = O.upsample2(x1) if ups else x1
@@ -120,7 +134,7 @@ def test_conv2d(case, device):
             y = torch.tanh(y)
         return y
 
-    check(f_prod, f_ref, inputs, device)
+    check(f_prod, f_ref, inputs, device, param_idx=(1, 2))
 
 
 @pytest.mark.parametrize('shape,relu', [((2, 16, 16, 64), True), ((3, 8, 8, 128), False), ((2, 32, 32, 64), True)])
@@ -133,7 +147,7 @@ def test_batchnorm_train(shape, relu, device):
     Pd = {}
 
     def f_prod(x, g, b):
-        return P.batchnorm(x, g, b, mm_p, mv_p, True, relu)
+        return P.batchnorm(x, g, b, mm_p, mv_p, True, relu, ggrad=g.gbuf, bgrad=b.gbuf, anchor=_anchor(x))
 
     def f_ref(x, g, b):
         Pd.update({'n/gamma': g, 'n/beta': b, 'n/moving_mean': mm0.double(), 'n/moving_variance': mv0.double()})
@@ -143,7 +157,7 @@ def test_batchnorm_train(shape, relu, device):
         f_ref.pre = y
         return torch.relu(y) if relu else y
 
-    check(f_prod, f_ref, [x, gamma, beta], device, rtol=5e-4)
+    check(f_prod, f_ref, [x, gamma, beta], device, rtol=5e-4, param_idx=(1, 2))
     _close(mm_p, Pd['n/moving_mean'], 'moving_mean')
     _close(mv_p, Pd['n/moving_variance'], 'moving_variance')
 
@@ -187,7 +201,8 @@ def test_dense(R, K, N, act, device):
         y = O.dense(x, w, b)
         return O.leaky_relu(y, 0.3) if act == 'leaky' else (torch.tanh(y) if act == 'tanh' else y)
 
-    check(lambda x, w, b: P.dense(x, w, b, act, 0.3), f_ref, [x, w, b], device)
+    check(lambda x, w, b: P.dense(x, w, b, act, 0.3, wgrad=w.gbuf, bgrad=b.gbuf, anchor=_anchor(x)), f_ref, [x, w, b], device,
+          param_idx=(1, 2))
 
 
 def test_film(device):
