@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: one DAFNet training iteration (BASELINE.json config[1]: dafnet_config_chaos, FiLM
+decoder, 256x256 two-modality slices, batch 8 per GPU, fp32).
+
+A "step" = DAFNetExecutor.train_batch = supervised_trainer.fit + 2 x D_Mask_trainer.fit + D_Image1/2_trainer.fit
+incl. the fake-pool generation, Adam updates and BatchNorm moving-average updates -- nothing is skipped.  Inputs
+(synthetic, seeded) are resident in HBM before the timed region.  Metric: paired 2-D slices per second, whole job.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Extra fields of the JSON line:
+  roofline     -- the implicit-GEMM convolution kernel (conv_fwd_kernel, used by forward and data-gradient launches):
+                  algorithmic FLOPs (2*M*K*N per launch, from the launch geometry) / time, both accumulated with HIP
+                  events around every such launch inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s)
+  cpu_baseline -- the oracle (torch-CPU restatement, "port") timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+TFLOP_PER_PAIR = {('film', 256): 1.630, ('spade', 256): 2.871}   # BASELINE.md section 4 (conv MACs x 2)
+
+
+class ConvTimer(object):
+    """HIP-event timing of every convolution launch on the compute stream (torch's current stream IS the stream
+    the kernels are launched on).  Events are only read after the timed region."""
+
+    def __init__(self):
+        self.records = []     # (kind, flops, start_event, end_event)
+        self.enabled = False
+
+    def install(self):
+        from multimodal_segmentation_amd import _native
+        self._orig = _native.call
+        timer = self
+
+        def call(name, *args):
+            if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_wgrad'):
+                if name == 'mmseg_conv2d_fwd':
+                    (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[6:16]
+                    flops = 2.0 * B * Ho * Wo * Cout * KH * KW * (C1 + C2)
+                    kind = 'conv_fwd_kernel'
+                else:
+                    (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[6:16]
+                    flops = 2.0 * B * Ho * Wo * Cout * KH * KW * (C1 + C2)
+                    kind = 'conv_wgrad_kernel'
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = timer._orig(name, *args)
+                e.record()
+                timer.records.append((kind, flops, s, e))
+                return rc
+            return timer._orig(name, *args)
+        _native.call = call
+
+    def summary(self):
+        out = {}
+        for kind, flops, s, e in self.records:
+            d = out.setdefault(kind, {'flops': 0.0, 'ms': 0.0, 'launches': 0})
+            d['flops'] += flops
+            d['ms'] += s.elapsed_time(e)
+            d['launches'] += 1
+        return out
+
+
+def cpu_baseline(H, decoder):
+    """The oracle ("port") on the host cores: one full DAFNet iteration (generator fit + 2 mask-D fits + 2 image-D
+    fits incl. pools) at the benchmark's image size with batch 1."""
+    from oracle import dafnet as OD, models as OM
+    from tests import helpers as Hh
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 1
+    P = OM.build_dafnet_params(10, H, H, decoder)
+    orc = OD.DAFNetOracle(P, dict(decoder_type=decoder))
+    d = Hh.to_torch(Hh.make_step_data(B, H, H, seed=99), torch.float32)
+    t0 = time.time()
+    orc.train_batch(d, supervised=True)
+    dt = time.time() - t0
+    return {'value': B / dt, 'unit': 'paired slices/s', 'cores': cores, 'kind': 'port',
+            'sample': 'one full DAFNet-%s iteration at %dx%d with batch 1 (torch-CPU oracle, fp32, %d threads): %.1f s'
+                      % (decoder, H, H, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--decoder', default='film', choices=['film', 'spade'])
+    ap.add_argument('--l_mix', type=float, default=1.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-conv-timer', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from multimodal_segmentation_amd import nn, _native
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos, dafnet_spade_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
+    from multimodal_segmentation_amd.parallel import dp
+    from multimodal_segmentation_amd.utils.config import EasyDict
+
+    _native.load()
+    nn.set_default_device('cuda:%d' % local_rank)
+    cfg = (dafnet_config_chaos if args.decoder == 'film' else dafnet_spade_config_chaos).get()
+    H = args.size
+    cfg['input_shape'] = (H, H, 1)
+    cfg['anatomy_encoder']['input_shape'] = (H, H, 1)
+    cfg['anatomy_encoder']['output_shape'] = (H, H, 8)
+    cfg['d_mask_params']['input_shape'] = (H, H, cfg['num_masks'])
+    cfg['d_image_params']['input_shape'] = (H, H, 1)
+    cfg['batch_size'] = args.batch
+    cfg['l_mix'] = args.l_mix
+    cfg['n_pairs'] = 1
+    cfg['folder'] = '/tmp/mmseg_bench'
+    conf = EasyDict(cfg)
+
+    model = DAFNet(conf)
+    model.build()
+    dp.enable(world > 1)
+    if world > 1:
+        all_models = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
+        dp.broadcast_models(all_models)
+    ex = DAFNetExecutor(conf, model)
+    ex.keep_losses_on_device = True
+    ex.init_train_data(device_resident=True, slices_per_volume=max(2, (2 * args.batch + 13) // 14))
+
+    timer = ConvTimer()
+    if not args.no_conv_timer:
+        timer.install()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    losses = {n: [] for n in ex.get_loss_names()}
+    for _ in range(args.warmup):
+        ex.train_batch(losses)
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ex.train_batch(losses)
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tmax = torch.tensor([dt], device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    passes = (1 if args.l_mix > 0 else 0) + (1 if args.l_mix < 1 else 0)
+    pairs = world * args.batch * args.steps * passes
+    value = pairs / dt
+    line = {
+        'metric': '2D slices/sec DAFNet train step, %dx%dx2-modality bs=%d/GPU' % (H, H, args.batch),
+        'value': value, 'unit': 'paired slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'DAFNet-%s (dafnet%s_config_chaos) %dx%d 2-modality training iteration: generator fit + '
+                               '2 mask-D fits + 2 image-D fits incl. fake pools, bs=%d/GPU, fp32, l_mix=%g'
+                               % (args.decoder, '' if args.decoder == 'film' else '_spade', H, H, args.batch, args.l_mix),
+                   'global_batch': world * args.batch, 'parallelism': 'dp%d' % world},
+    }
+    key = (args.decoder, H)
+    if key in TFLOP_PER_PAIR:
+        line['conv_tflops_whole_step'] = TFLOP_PER_PAIR[key] * value / world
+        line['conv_roofline_frac_whole_step'] = TFLOP_PER_PAIR[key] * value / world / FP32_MFMA_PEAK_TFLOPS
+    if rank == 0:
+        summ = timer.summary() if not args.no_conv_timer else {}
+        k = summ.get('conv_fwd_kernel')
+        if k:
+            ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
+            line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (implicit-GEMM fp32 MFMA; forward + data-gradient launches)',
+                                'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                                'traffic': None, 'launches': k['launches'], 'avg_launch_ms': k['ms'] / k['launches'],
+                                'gpu_ms_per_step': k['ms'] / args.steps}
+        w = summ.get('conv_wgrad_kernel')
+        if w:
+            ach = w['flops'] / (w['ms'] * 1e-3) / 1e12
+            line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv_wgrad_kernel (+ slab reduce)', 'achieved': ach,
+                                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                                      'launches': w['launches'], 'gpu_ms_per_step': w['ms'] / args.steps}
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(H, args.decoder)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
