@@ -49,7 +49,11 @@ class ConvTimer(object):
             if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_wgrad'):
                 if name == 'mmseg_conv2d_fwd':
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[6:16]
-                    flops = 2.0 * B * Ho * Wo * Cout * KH * KW * (C1 + C2)
+                    transposed = args[20]
+                    # algorithmic FLOPs: a fractionally-strided (data-gradient) launch only has the taps of the strided
+                    # forward convolution it differentiates, i.e. B*H*W (its INPUT pixels) x KH*KW x Cin x Cout
+                    pix = B * H * W if transposed else B * Ho * Wo
+                    flops = 2.0 * pix * Cout * KH * KW * (C1 + C2)
                     kind = 'conv_fwd_kernel'
                 else:
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[6:16]

@@ -59,7 +59,8 @@ int mmseg_act_bwd(const float* dy, const float* y, float* dx, long n, int act, f
 int mmseg_axpby(const float* a, const float* b, float* out, long n, float sa, float sb, void* stream);
 int mmseg_fill(float* x, long n, float v, void* stream);
 int mmseg_colsum_blocks(long M);
-/* out[c] (+)= scale * sum_m x[m][c]; ws: mmseg_colsum_blocks(M)*C floats.  (bias gradients) */
+long mmseg_colsum_workspace_floats(long M, int C);
+/* out[c] (+)= scale * sum_m x[m][c]; ws: mmseg_colsum_workspace_floats(M, C) floats.  (bias gradients) */
 int mmseg_colsum(const float* x, float* out, float* ws, long M, int C, float scale, int accumulate, void* stream);
 /* keras MaxPooling2D(2) (models/unet.py:39-51, layers/stn_spline.py:108,111) */
 int mmseg_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);

@@ -419,19 +419,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(WgradParams q)
     }
 }
 
-// dW[i] = sum_s ws[s][i]   (fixed order -> deterministic)
-__global__ void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n, int S) {
-    const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+// dW[i] = sum_s ws[s][i]   (fixed order -> deterministic).  block = 64 float4 columns x 4 slab lanes
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n, int S) {
+    __shared__ f32x4 sm[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i4 = ((long)blockIdx.x * 64 + cl) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (i4 + 3 < n) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < S; ++s) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i4);
-        *reinterpret_cast<f32x4*>(out + i4) = a;
+#pragma unroll 4
+        for (int s = sl; s < S; s += 4) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i4);
     } else {
-        for (long i = i4; i < n; ++i) {
-            float a = 0.f;
-            for (int s = 0; s < S; ++s) a += ws[(size_t)s * n + i];
-            out[i] = a;
-        }
+        for (int s = sl; s < S; s += 4)
+            for (int e = 0; e < 4; ++e) if (i4 + e < n) a[e] += ws[(size_t)s * n + i4 + e];
+    }
+    sm[sl][cl] = a;
+    __syncthreads();
+    if (sl == 0) {
+        const f32x4 t = sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl];
+        if (i4 + 3 < n) *reinterpret_cast<f32x4*>(out + i4) = t;
+        else for (int e = 0; e < 4; ++e) if (i4 + e < n) out[i4 + e] = t[e];
     }
 }
 
@@ -517,10 +523,8 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     if (Cout > 32) rc = launch_wgrad<128, 64, 2, 2>(q, S, vec, st);
     else rc = launch_wgrad<128, 32, 4, 1>(q, S, vec, st);
     if (rc != 0 || S == 1) return rc;
-    const int threads = 256;
     const long n4 = (KN + 3) / 4;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + threads - 1) / threads)), dim3(threads), 0, st,
-                       (const float*)ws, dw, KN, S);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, (const float*)ws, dw, KN, S);
     return MMSEG_CHECK_LAUNCH();
 }
 

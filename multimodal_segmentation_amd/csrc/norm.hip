@@ -54,15 +54,79 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, const float* __re
     }
 }
 
-// training statistics -> mean, invstd, fused scale/shift, moving-average update
+// Fast path for C % 64 == 0 (every BatchNorm of the models): grid (row blocks, C/64); a block is 16 float4 column
+// lanes x 16 row lanes, so a wave reads 4 rows x 256 contiguous bytes per load instruction; the row loop is unrolled
+// to keep >= 4 independent 16-byte loads per lane in flight (HBM-bound streaming, ~32 KB in flight per CU).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ part,
+                                                            long M, int C, long rows_per_block, int relu) {
+    __shared__ f32x4 sm[2][16][16];
+    const int tid = threadIdx.x, c4 = tid & 15, rl = tid >> 4;
+    const int C4 = C >> 2;
+    const int col = blockIdx.y * 16 + c4;           // float4 column
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const f32x4* X = reinterpret_cast<const f32x4*>(x);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+        const f32x4 sh = X[col];
+#pragma unroll 4
+        for (long r = r0 + rl; r < r1; r += 16) {
+            const f32x4 d = X[r * C4 + col] - sh;
+            s1 += d; s2 += d * d;
+        }
+    } else {
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[col], is = reinterpret_cast<const f32x4*>(invstd)[col];
+        const f32x4* DY = reinterpret_cast<const f32x4*>(dy);
+        const f32x4* Y = reinterpret_cast<const f32x4*>(y);
+#pragma unroll 4
+        for (long r = r0 + rl; r < r1; r += 16) {
+            f32x4 g = DY[r * C4 + col];
+            if (relu) {
+                const f32x4 o = Y[r * C4 + col];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+            }
+            s1 += g; s2 += g * (X[r * C4 + col] - mu) * is;
+        }
+    }
+    sm[0][rl][c4] = s1; sm[1][rl][c4] = s2;
+    __syncthreads();
+    if (tid < 32) {                                   // 16 columns x {s1, s2}
+        const int which = tid >> 4, cc = tid & 15;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[which][k][cc];
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + which) * C + (size_t)(blockIdx.y * 16 + cc) * 4) = t;
+    }
+}
+
+// sum the per-block partials of 64 channels with 4 lanes per channel (blockDim 256); result valid where lane == 0
+__device__ __forceinline__ void reduce_partials_64x4(const float* __restrict__ part, int nblk, int C, int c, int lane,
+                                                     float& s1, float& s2, float* sm /* 512 floats */) {
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int b = lane; b < nblk; b += 4) { a1 += part[((size_t)b * 2) * C + c]; a2 += part[((size_t)b * 2 + 1) * C + c]; }
+    }
+    sm[threadIdx.x] = a1; sm[256 + threadIdx.x] = a2;
+    __syncthreads();
+    const int cl = threadIdx.x & 63;
+    s1 = sm[cl] + sm[64 + cl] + sm[128 + cl] + sm[192 + cl];
+    s2 = sm[256 + cl] + sm[320 + cl] + sm[384 + cl] + sm[448 + cl];
+}
+
+// training statistics -> mean, invstd, fused scale/shift, moving-average update.  grid = ceil(C/64), block 256
 __global__ void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,
                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mov_mean,
                                       float* __restrict__ mov_var, int nblk, int C, long M, float eps, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) { s1 += part[((size_t)b * 2) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
+    __shared__ float sm[512];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s1, s2;
+    reduce_partials_64x4(part, nblk, C, c, lane, s1, s2, sm);
+    if (c >= C || lane != 0) return;
     const float invM = 1.f / (float)M;
     const float d = s1 * invM;
     const float mu = x[c] + d;
@@ -109,10 +173,11 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 __global__ void bn_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                     float* __restrict__ coef /* [3][C] */, int nblk, int C, long M) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) { s1 += part[((size_t)b * 2) * C + c]; s2 += part[((size_t)b * 2 + 1) * C + c]; }
+    __shared__ float sm[512];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s1, s2;
+    reduce_partials_64x4(part, nblk, C, c, lane, s1, s2, sm);
+    if (c >= C || lane != 0) return;
     dbeta[c] = s1; dgamma[c] = s2;
     const float invM = 1.f / (float)M, is = invstd[c], ga = gamma[c], mu = mean[c];
     const float A = ga * is;
@@ -234,6 +299,16 @@ __global__ void in_bwd_apply_kernel(const float* __restrict__ dxn, const float* 
     }
 }
 
+// row blocks of the float4 fast path: ~1024 blocks in total, at most 512 row blocks, at least 64 rows per block
+static inline int v4_row_blocks(long M, int C) {
+    long nb = 1024 / (C / 64);
+    if (nb > 512) nb = 512;
+    const long maxb = (M + 63) / 64;
+    if (nb > maxb) nb = maxb;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
 static inline int ew_grid(long n) {
     long b = (n + 255) / 256;
     if (b > 4096) b = 4096;
@@ -249,11 +324,19 @@ int mmseg_norm_workspace_floats(int C) { return NORM_MAX_BLOCKS * 2 * C; }
 int mmseg_bn_stats(const float* x, const float* gamma, const float* beta, float* mean, float* invstd, float* scale, float* shift,
                    float* mov_mean, float* mov_var, float* ws, long M, int C, float eps, float momentum, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = norm_blocks(M);
-    const long rpb = (M + nblk - 1) / nblk;
-    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, ws, M, C, rpb, 0);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, x, gamma, beta, mean, invstd,
+    int nblk;
+    if ((C & 63) == 0) {
+        nblk = v4_row_blocks(M, C);
+        const long rpb = (M + nblk - 1) / nblk;
+        hipLaunchKernelGGL(bn_partial_v4_kernel<0>, dim3(nblk, C / 64), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, ws, M, C, rpb, 0);
+    } else {
+        nblk = norm_blocks(M);
+        const long rpb = (M + nblk - 1) / nblk;
+        hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, ws, M, C, rpb, 0);
+    }
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, x, gamma, beta, mean, invstd,
                        scale, shift, mov_mean, mov_var, nblk, C, M, eps, momentum);
     return MMSEG_CHECK_LAUNCH();
 }
@@ -273,10 +356,17 @@ int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* g
                  float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, void* stream) {
     if (C & 3) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = norm_blocks(M);
-    const long rpb = (M + nblk - 1) / nblk;
-    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M);
+    int nblk;
+    if ((C & 63) == 0) {
+        nblk = v4_row_blocks(M, C);
+        const long rpb = (M + nblk - 1) / nblk;
+        hipLaunchKernelGGL(bn_partial_v4_kernel<1>, dim3(nblk, C / 64), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
+    } else {
+        nblk = norm_blocks(M);
+        const long rpb = (M + nblk - 1) / nblk;
+        hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
+    }
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M);
     const long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y, x, (const float*)coef, dx, n4, C / 4, relu);
     return MMSEG_CHECK_LAUNCH();

@@ -74,6 +74,42 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __rest
     }
 }
 
+// float4 fast path: x viewed as [M][C] with C % 64 == 0; grid (row blocks, C/64), block = 16 float4 columns x 16 row lanes
+__global__ __launch_bounds__(256) void colsum_v4_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long M, int C,
+                                                                long rows_per_block) {
+    __shared__ f32x4 sm[16][16];
+    const int tid = threadIdx.x, c4 = tid & 15, rl = tid >> 4;
+    const int C4 = C >> 2, col = blockIdx.y * 16 + c4;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const f32x4* X = reinterpret_cast<const f32x4*>(x);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (long r = r0 + rl; r < r1; r += 16) s += X[r * C4 + col];
+    sm[rl][c4] = s;
+    __syncthreads();
+    if (tid < 16) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][tid];
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + (size_t)(blockIdx.y * 16 + tid) * 4) = t;
+    }
+}
+// out[c] = scale * sum over blocks and over the pseudo-channels p = j*C + c of a [.][CP] partial table (CP = 64 when
+// a small-C tensor was re-viewed as 64 pseudo-channels, CP = C otherwise).  one block per output channel.
+__global__ void colsum_fold_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C, int CP,
+                                         float scale, int accumulate) {
+    __shared__ float red[17];
+    const int c = blockIdx.x, groups = CP / C;
+    const int total = groups * nblk;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int j = i % groups, b = i / groups;
+        a += part[(size_t)b * CP + j * C + c];
+    }
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + a * scale : a * scale;
+}
+
 __global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C,
                                     float scale, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,12 +388,29 @@ int mmseg_colsum_blocks(long M) {
     if (nb < 1) nb = 1;
     return (int)nb;
 }
+// workspace floats for any path of mmseg_colsum: <= 512 row blocks x max(C, 64) pseudo-channels, or 1024 x C
+long mmseg_colsum_workspace_floats(long M, int C) { (void)M; const long a = 1024L * C; return a > 65536 ? a : 65536; }
 int mmseg_colsum(const float* x, float* out, float* ws, long M, int C, float scale, int accumulate, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    long M2 = 0; int C2 = 0;
+    if (aligned && (C & 63) == 0) { M2 = M; C2 = C; }
+    else if (aligned && C <= 32 && 64 % C == 0 && (M * C) % 64 == 0) { M2 = M * C / 64; C2 = 64; }
+    if (C2) {
+        long nb = 1024 / (C2 / 64);
+        if (nb > 512) nb = 512;
+        const long maxb = (M2 + 63) / 64;
+        if (nb > maxb) nb = maxb;
+        if (nb < 1) nb = 1;
+        const long rpb = (M2 + nb - 1) / nb;
+        hipLaunchKernelGGL(colsum_v4_partial_kernel, dim3((unsigned)nb, C2 / 64), dim3(256), 0, st, x, ws, M2, C2, rpb);
+        hipLaunchKernelGGL(colsum_fold_final_kernel, dim3(C), dim3(256), 0, st, (const float*)ws, out, (int)nb, C, C2, scale, accumulate);
+        return MMSEG_CHECK_LAUNCH();
+    }
     const int nblk = mmseg_colsum_blocks(M);
     const long rpb = (M + nblk - 1) / nblk;
-    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 256 * sizeof(float), st, x, ws, M, C, rpb);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, out, nblk, C, scale, accumulate);
+    hipLaunchKernelGGL(colsum_fold_final_kernel, dim3(C), dim3(256), 0, st, (const float*)ws, out, nblk, C, C, scale, accumulate);
     return MMSEG_CHECK_LAUNCH();
 }
 

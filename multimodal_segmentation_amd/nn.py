@@ -277,11 +277,14 @@ def bn_params(m, name, c):
     m.add_param(name + '/moving_variance', (c,), 'ones', trainable=False)
 
 
-def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False):
+def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False, bias_grad=True):
+    """bias_grad=False: the convolution feeds a training-mode BatchNorm, whose backward output sums to zero over
+    (N,H,W) per channel, so the bias gradient is EXACTLY zero in exact arithmetic (the reference accumulates only
+    rounding noise there); the column-sum pass over the gradient tensor is skipped and the bias keeps its value."""
     w = m.params[name + '/kernel']
     b = m.params.get(name + '/bias')
     return ops.conv2d(x, w.data, b.data if b is not None else None, stride, padding, act, alpha, x2, upsample,
-                      wgrad=w.g(), bgrad=b.g() if b is not None else None, anchor=anchor(x.device))
+                      wgrad=w.g(), bgrad=b.g() if (b is not None and bias_grad) else None, anchor=anchor(x.device))
 
 
 def dense(m, name, x, act=None, alpha=0.0):

@@ -110,7 +110,7 @@ class _Conv2d(torch.autograd.Function):
         dx1 = dx2 = None
         M = B * Ho * Wo
         if ctx.bgrad is not None:
-            ws = _ws('colsum', N.call('mmseg_colsum_blocks', M) * Cout, dy.device)
+            ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', M, Cout), dy.device)
             N.call('mmseg_colsum', g, ctx.bgrad, ws, M, Cout, 1.0, 1)
         if ctx.wgrad is not None:
             dw = _ws('dw_tmp', w.numel(), dy.device)[:w.numel()]
@@ -360,7 +360,7 @@ class _Dense(torch.autograd.Function):
             N.call('mmseg_dense_wgrad', x, g, dw, R, K, Nn)
             _accumulate(ctx.wgrad.view(-1), dw)
         if ctx.bgrad is not None:
-            ws = _ws('colsum', N.call('mmseg_colsum_blocks', R) * Nn, x.device)
+            ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', R, Nn), x.device)
             N.call('mmseg_colsum', g, ctx.bgrad, ws, R, Nn, 1.0, 1)
         return (dx,) + (None,) * 7
 

@@ -102,6 +102,10 @@ def fill(x, n, v):
     x.fill_(v); return 0
 
 
+def colsum_workspace_floats(M, C):
+    return 1
+
+
 def colsum_blocks(M):
     return 1
 

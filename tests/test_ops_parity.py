@@ -104,6 +104,8 @@ CONV_CASES = [
     (1, 12, 12, 1, 0, 64, 4, 2, 'valid', 'leaky', False),
     (2, 8, 8, 256, 0, 512, 3, 1, 'same', None, False),
     (3, 128, 128, 64, 0, 128, 3, 1, 'same', 'relu', False),
+    (2, 128, 128, 8, 0, 8, 3, 1, 'same', 'leaky', False),      # large M, tiny C: folded column-sum path
+    (2, 96, 96, 64, 0, 5, 1, 1, 'same', None, False),          # large M, C not dividing 64: generic column sums
 ]
 
 

@@ -1,0 +1,184 @@
+"""Known-answer tests that pin the oracle (and the host-side helpers of the product) from the maths, since the
+reference has no tests of its own."""
+import math
+import os
+
+import numpy as np
+import torch
+
+from oracle import ops as O
+from oracle import models as M
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_helpers.npz')
+
+
+def test_golden_pool_sampling_and_normal_draws():
+    """utils/data_utils.py::sample and utils/distributions.py of the reference, captured under fixed seeds."""
+    from multimodal_segmentation_amd.utils import data_utils
+    from multimodal_segmentation_amd.utils.distributions import NormalDistribution
+    g = np.load(GOLD)
+    pool = g['pool']
+    for seed in (0, 1, 1234):
+        np.random.seed(seed)
+        assert np.array_equal(data_utils.sample(pool, 8), g['sample_seed%d' % seed])
+        assert np.array_equal(NormalDistribution().sample((4, 8)), g['normal_seed%d' % seed])
+        np.random.seed(seed)
+        idx = data_utils.sample_indices(len(pool), 8)
+        assert np.array_equal(pool[idx], g['sample_seed%d' % seed])
+    assert np.array_equal(data_utils.sample(pool, 5, seed=7), g['sample_seedarg7'])
+
+
+def test_rounding_half_to_even_and_ste():
+    x = torch.tensor([0.5, 1.5, 2.5, -0.5, 0.49999, 0.50001], dtype=torch.float64, requires_grad=True)
+    y = O.round_ste(x)
+    assert y.tolist() == [0.0, 2.0, 2.0, -0.0, 0.0, 1.0]
+    y.sum().backward()
+    assert x.grad.tolist() == [1.0] * 6
+
+
+def test_tps_identity_and_closed_form():
+    H, W = 12, 10
+    vol = torch.rand(2, H, W, 8, dtype=torch.float64)
+    out = O.tps_warp(vol, torch.zeros(2, 25, 2, dtype=torch.float64))
+    assert (out - vol).abs().max() < 1e-9                       # theta = 0 is the identity warp
+    theta = torch.randn(2, 25, 2, dtype=torch.float64) * 0.05
+    Mb = O.tps_basis(H, W)
+    assert (Mb.sum(1) - 1).abs().max() < 1e-9                   # rows sum to one (TPS reproduces constants)
+    q = O.nd_grid((H, W), torch.float64)[0]
+    loc_closed = q[None] + torch.einsum('pj,bjk->bpk', Mb, theta)
+    cp = O.nd_grid((5, 5), torch.float64)
+    loc_solve = torch.stack([O.interpolate_spline(cp, cp + theta[i][None], q[None])[0] for i in range(2)])
+    assert (loc_closed - loc_solve).abs().max() < 1e-10          # loc = grid + M @ theta  
+    # the product's host-side basis (numpy) equals the oracle's (torch)
+    from multimodal_segmentation_amd.layers.stn_spline import tps_basis
+    assert np.abs(tps_basis((H, W), (5, 5)) - Mb.numpy()).max() < 1e-10
+
+
+def test_resampler_integer_locations_and_zero_fill():
+    data = torch.arange(2 * 4 * 5 * 1, dtype=torch.float64).reshape(2, 4, 5, 1)
+    warp = torch.tensor([[[1., 2.], [4., 3.], [5., 0.], [-1., 0.], [0.5, 0.]]] * 2, dtype=torch.float64)
+    out = O.resampler(data, warp)
+    assert out[0, 0, 0] == data[0, 2, 1, 0]                      # (x=1, y=2) -> row 2, col 1
+    assert out[0, 1, 0] == data[0, 3, 4, 0]
+    assert out[0, 2, 0] == 0 and out[0, 3, 0] == 0               # outside the image
+    assert out[0, 4, 0] == 0.5 * (data[0, 0, 0, 0] + data[0, 0, 1, 0])
+
+
+def test_nearest_resize_index_rule():
+    x = torch.arange(8 * 8, dtype=torch.float64).reshape(1, 8, 8, 1)
+    y = O.resize_nearest(x, 4, 4)
+    assert torch.equal(y[0, :, :, 0], x[0, ::2, ::2, 0])         # src = floor(dst * 2)
+    assert torch.equal(O.resize_nearest(x, 8, 8), x)
+
+
+def test_spectral_power_iteration_vs_numpy_and_svd():
+    rng = np.random.RandomState(0)
+    W = rng.standard_normal((4, 4, 8, 16)) * 0.1
+    u0 = rng.random_sample((128, 1)) * 2 - 1
+    x = W.reshape(-1, 16)
+    u = u0.copy()
+    for _ in range(3):                                           # explicit loop, spectralnorm.py:228-234
+        wtu = x.T @ u
+        v = wtu / np.sqrt((wtu ** 2).sum())
+        wv = x @ v
+        u = wv / np.sqrt((wv ** 2).sum())
+    sigma = float(u.T @ x @ v)
+    expect = 10.0 * np.abs(x / sigma - x).mean()
+    got = O.spectral_reg(torch.tensor(W), torch.tensor(u0), 10.0)
+    assert abs(float(got) - expect) < 1e-12
+    assert sigma <= np.linalg.svd(x, compute_uv=False)[0] + 1e-12     # a lower bound that converges to sigma_max
+    assert sigma > 0.8 * np.linalg.svd(x, compute_uv=False)[0]
+    # gradient: (alpha / N) * sign(W - W / sigma), sigma under stop_gradient
+    Wt = torch.tensor(W, requires_grad=True)
+    O.spectral_reg(Wt, torch.tensor(u0), 10.0).backward()
+    assert np.allclose(Wt.grad.numpy(), 10.0 / W.size * np.sign(W - W / sigma))
+
+
+def test_dice_and_swapped_bce_hand_values():
+    t = torch.zeros(1, 2, 2, 3, dtype=torch.float64)
+    t[0, 0, 0, 0] = 1; t[0, 0, 1, 1] = 1; t[0, 1, 0, 2] = 1; t[0, 1, 1, 2] = 1
+    p = torch.full((1, 2, 2, 3), 1.0 / 3, dtype=torch.float64)
+    # dice over the first 2 channels: I = 2/3, sum_t = 2, sum_p = 8/3
+    assert abs(float(O.dice_loss(t, p, 2)) - (1 - (2 * (2 / 3) + 1e-12) / (2 + 8 / 3 + 1e-12))) < 1e-12
+    # swapped-argument BCE (costs.py:70,134): weights from the predictions, log of the labels
+    n = p.sum((0, 1, 2)); w = n.sum() / (n + 1e-12)
+    expect = -(p * torch.log(t + 1e-12) * w).sum(-1).mean()
+    assert abs(float(O.weighted_cross_entropy_loss(t, p)) - float(expect)) < 1e-12
+    # closed form: 27.631 * sum_c w_c p_c (1 - t_c) averaged over pixels
+    closed = 27.631021115928547 * (w * p * (1 - t)).sum(-1).mean()
+    assert abs(float(expect) - float(closed)) < 1e-9
+    assert abs(float(O.combined_dice_bce(t, p, 2)) - float(O.dice_loss(t, p, 2) + 0.01 * expect)) < 1e-12
+
+
+def test_kl_film_spade_closed_forms():
+    mu, lv = torch.tensor([[0.5, -1.0]]), torch.tensor([[0.2, -0.3]])
+    kl = -0.5 * (1 + 0.2 - 0.25 - math.exp(0.2) + 1 - 0.3 - 1.0 - math.exp(-0.3))
+    assert abs(float(O.kl(mu, lv)) - kl) < 1e-6
+    x = torch.ones(1, 2, 2, 2)
+    assert torch.equal(O.film(x, torch.tensor([[2., 3.]]), torch.tensor([[1., -1.]]))[0, 0, 0], torch.tensor([3., 2.]))
+    assert torch.equal(O.spade_cond(x, x * 0.5, x * 2), x * 1.5 + 2)
+
+
+def test_instance_norm_joint_statistics():
+    x = torch.randn(2, 4, 4, 3, dtype=torch.float64)
+    y = O.instance_norm(x)
+    for b in range(2):
+        xb = x[b].numpy()
+        assert np.allclose(y[b].numpy(), (xb - xb.mean()) / (xb.std() + 1e-3))
+
+
+def test_keras_adam_three_step_trace():
+    P = {'p': torch.tensor([1.0, -2.0], dtype=torch.float64)}
+    opt = O.KerasAdam(0.1)
+    p, m, v = np.array([1.0, -2.0]), np.zeros(2), np.zeros(2)
+    for t in range(1, 4):
+        g = np.array([0.5 * t, -1.0])
+        opt.step(P, {'p': torch.tensor(g)})
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g * g
+        lr_t = 0.1 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        p = p - lr_t * m / (np.sqrt(v) + 1e-7)                   # eps OUTSIDE the sqrt, 1e-7 (Keras 2.1.6)
+        assert np.allclose(P['p'].numpy(), p, atol=1e-12)
+
+
+def test_batchnorm_training_and_moving_update():
+    x = torch.randn(4, 3, 3, 5, dtype=torch.float64)
+    P = {'n/gamma': torch.ones(5, dtype=torch.float64) * 2, 'n/beta': torch.ones(5, dtype=torch.float64),
+         'n/moving_mean': torch.zeros(5, dtype=torch.float64), 'n/moving_variance': torch.ones(5, dtype=torch.float64)}
+    upd = []
+    y = O.batchnorm(x, P, 'n', True, upd)
+    xn = x.reshape(-1, 5).numpy()
+    assert np.allclose(y.reshape(-1, 5).numpy(), (xn - xn.mean(0)) / np.sqrt(xn.var(0) + 1e-3) * 2 + 1)
+    O.apply_bn_updates(P, upd)
+    assert np.allclose(P['n/moving_mean'].numpy(), 0.01 * xn.mean(0))
+    assert np.allclose(P['n/moving_variance'].numpy(), 0.99 + 0.01 * xn.var(0, ddof=1))
+
+
+def test_parameter_counts_match_the_shape_walk():
+    """structural check of the graphs at 256x256."""
+    P = M.build_dafnet_params(10, 256, 256)
+    cnt = lambda pre: sum(v.numel() for k, v in P.items() if k.startswith(pre) and not k.endswith('/u0'))
+    assert cnt('EA0/') == 4691904 and cnt('EAS/') == 29848136 and cnt('EM/') == 1020464
+    assert cnt('SEG/') == 42437 and cnt('DEC/') == 5841 and cnt('FUS/') == 6531210
+    assert cnt('DM/') == 3130817 and cnt('DI1/') == 3127745
+    P2 = M.build_dafnet_params(10, 256, 256, 'spade')
+    assert sum(v.numel() for k, v in P2.items() if k.startswith('DEC/')) == 4317905
+
+
+def test_two_independent_restatements_of_conv_and_maxpool():
+    """torch F.conv2d restatement vs explicit numpy loops."""
+    rng = np.random.RandomState(1)
+    x = rng.standard_normal((1, 5, 6, 2)); w = rng.standard_normal((3, 3, 2, 3)); b = rng.standard_normal(3)
+    y = O.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(b)).numpy()
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    ref = np.zeros((1, 5, 6, 3))
+    for i in range(5):
+        for j in range(6):
+            ref[0, i, j] = np.einsum('hwc,hwco->o', xp[0, i:i + 3, j:j + 3], w) + b
+    assert np.abs(y - ref).max() < 1e-10
+    y2 = O.conv2d(torch.tensor(x), torch.tensor(w), None, stride=2, padding='valid').numpy()
+    for i in range(2):
+        for j in range(2):
+            assert np.abs(y2[0, i, j] - np.einsum('hwc,hwco->o', x[0, 2 * i:2 * i + 3, 2 * j:2 * j + 3], w)).max() < 1e-10
+    mp = O.maxpool2(torch.tensor(x[:, :4, :6])).numpy()
+    assert np.allclose(mp[0, 1, 2], x[0, 2:4, 4:6].max((0, 1)))
