@@ -256,6 +256,195 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvParams p) {
     }
 }
 
+// =====================================================================================
+// Fast path of the same implicit GEMM for the layers that carry the FLOPs (every conv with Cin % 32 == 0 that is
+// not a fractionally-strided data gradient: the UNet, segmentor c1, discriminator blocks, SPADE convs and all
+// stride-1 data gradients).  Differences to conv_fwd_kernel:
+//   * a 32-wide K tile lies inside ONE filter tap and ONE input tensor, so tap / channel / source bookkeeping is
+//     wave-uniform scalar arithmetic done once per K tile instead of per lane and row;
+//   * the gather uses buffer loads with 32-bit offsets: a padding tap simply gets an out-of-range offset and the
+//     hardware returns zeros -- no divergent branches, ~10 VALU per 16-byte load instead of ~100;
+//   * LDS is double buffered: the next tile is written while the current one feeds the MFMAs, one barrier per K tile.
+// =====================================================================================
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define BUF_OOB 0x7ffffff0
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_RPP = NT / 8, A_F4 = BM / A_RPP;
+    constexpr int BF4_PER_ROW = BN / 4, B_RPP = NT / BF4_PER_ROW, B_F4 = (BK + B_RPP - 1) / B_RPP;
+    constexpr int BS_LD = BN + 4;
+    constexpr int A_SZ = BM * AS_LD, B_SZ = BK * BS_LD;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+    float* As = smem;
+    float* Bs = smem + 2 * A_SZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lb / ntn) * BM, n0 = (lb % ntn) * BN;
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
+                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.K * p.Cout * 4, 0x00020000);
+
+    // ---- per-thread row state: element offsets of (b, hb, wb, 4*kc) in x1 / x2 ------------------------------
+    const int kc = tid & 7, ar0 = tid >> 3;
+    int a_hb[A_F4], a_wb[A_F4], a_o1[A_F4], a_o2[A_F4];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) {
+        const int m = m0 + ar0 + j * A_RPP;
+        if (m < p.M) {
+            const int b = m / HoWo, r = m - b * HoWo;
+            const int ho = r / p.Wo, wo = r - ho * p.Wo;
+            const int hb = ho * p.stride - p.pad_h, wb = wo * p.stride - p.pad_w;
+            a_hb[j] = hb; a_wb[j] = wb;
+            a_o1[j] = p.ups ? b * p.H1 : ((b * p.H + hb) * p.W + wb) * p.C1 + 4 * kc;
+            a_o2[j] = ((b * p.H + hb) * p.W + wb) * p.C2 + 4 * kc;
+        } else {
+            a_hb[j] = -(1 << 28); a_wb[j] = -(1 << 28); a_o1[j] = 0; a_o2[j] = 0;
+        }
+    }
+    const int Cin = p.C1 + p.C2;
+    int s_c0 = 0, s_kh = 0, s_kw = 0;          // wave-uniform position of the next K tile: channel base, tap
+    const int b_nc = tid % BF4_PER_ROW, b_r0 = tid / BF4_PER_ROW;
+    const int b_n = n0 + 4 * b_nc;
+    const int b_off0 = (b_n < p.Cout) ? (b_r0 * p.Cout + b_n) * 4 : BUF_OOB;
+    int b_koff = 0;                            // byte offset of the K tile's first weight row
+
+    f32x4 ra[A_F4], rb[B_F4];
+    auto load_tile = [&]() {
+        const int kh = s_kh, kw = s_kw;
+        if (s_c0 < p.C1) {
+            if (p.ups) {
+#pragma unroll
+                for (int j = 0; j < A_F4; ++j) {
+                    const int hi = a_hb[j] + kh, wi = a_wb[j] + kw;
+                    const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    const int off = ((a_o1[j] + (hi >> 1)) * p.W1 + (wi >> 1)) * p.C1 + s_c0 + 4 * kc;
+                    ra[j] = buf_load4(r1, ok ? off * 4 : BUF_OOB);
+                }
+            } else {
+                const int toff = (kh * p.W + kw) * p.C1 + s_c0;
+#pragma unroll
+                for (int j = 0; j < A_F4; ++j) {
+                    const int hi = a_hb[j] + kh, wi = a_wb[j] + kw;
+                    const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                    ra[j] = buf_load4(r1, ok ? (a_o1[j] + toff) * 4 : BUF_OOB);
+                }
+            }
+        } else {
+            const int toff = (kh * p.W + kw) * p.C2 + (s_c0 - p.C1);
+#pragma unroll
+            for (int j = 0; j < A_F4; ++j) {
+                const int hi = a_hb[j] + kh, wi = a_wb[j] + kw;
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                ra[j] = buf_load4(r2, ok ? (a_o2[j] + toff) * 4 : BUF_OOB);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) {
+            const int kr = j * B_RPP;           // b_r0 already folded into b_off0
+            rb[j] = (b_r0 + kr < BK) ? buf_load4(rw, b_off0 == BUF_OOB ? BUF_OOB : b_off0 + b_koff + kr * p.Cout * 4)
+                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // advance the uniform K position by one tile
+        b_koff += BK * p.Cout * 4;
+        s_c0 += BK;
+        if (s_c0 >= Cin) { s_c0 = 0; if (++s_kw == p.KW) { s_kw = 0; ++s_kh; } }
+    };
+    auto store_tile = [&](int buf) {
+        float* A = As + buf * A_SZ;
+        float* Bt = Bs + buf * B_SZ;
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j)
+            *reinterpret_cast<f32x4*>(&A[(ar0 + j * A_RPP) * AS_LD + 4 * kc]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) {
+            const int kr = b_r0 + j * B_RPP;
+            if (kr < BK) *reinterpret_cast<f32x4*>(&Bt[kr * BS_LD + 4 * b_nc]) = rb[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = p.K / BK;
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    const int a_row = wm * (BM / WM) + li;
+    const int b_col = wn * (BN / WN) + li;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile();          // buffer loads in flight under the MFMAs
+        const float* A = As + cur * A_SZ;
+        const float* Bt = Bs + cur * B_SZ;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(&A[(a_row + i * 32) * AS_LD + 8 * q + 4 * lh]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float b[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bt[(8 * q + 4 * lh + t) * BS_LD + b_col + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);  // the other buffer was last read one iteration ago (barrier below)
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + li;
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                const float v = act_apply(acc[i][j][r] + bv, p.act, p.alpha);
+                if (p.y2 == nullptr) p.y[(size_t)m * p.Cout + n] = v;
+                else if (n < p.nsplit1) p.y[(size_t)m * p.nsplit1 + n] = v;
+                else p.y2[(size_t)m * (p.Cout - p.nsplit1) + (n - p.nsplit1)] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_fast(const ConvParams& p, hipStream_t st) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
+    return MMSEG_CHECK_LAUNCH();
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
@@ -271,6 +460,19 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (p.M <= 0 || p.Cout <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
     const bool vec = (p.C1 % 4 == 0) && (p.C2 % 4 == 0) && aligned16(p.x1) && (p.C2 == 0 || aligned16(p.x2));
     const long tiles_big = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+    const long lim = (1L << 31) - 64;
+    const bool fast = vec && !p.transposed && (p.C1 % 32 == 0) && (p.C2 % 32 == 0) && (p.Cout % 4 == 0) && aligned16(p.w) &&
+                      (long)p.B * p.H1 * p.W1 * p.C1 * 4 < lim && (long)p.B * p.H * p.W * p.C2 * 4 < lim &&
+                      (long)p.K * p.Cout * 4 < lim;
+    if (fast) {
+        if (p.Cout > 64 && tiles_big >= 384) return launch_fast<128, 128, 2, 2>(p, st);
+        if (p.Cout > 32) {
+            const long tiles_mid = (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
+            if (tiles_mid >= 384) return launch_fast<128, 64, 2, 2>(p, st);
+            return launch_fast<64, 64, 2, 2>(p, st);
+        }
+        return launch_fast<128, 32, 4, 1>(p, st);
+    }
     if (p.Cout > 64 && tiles_big >= 384) return launch_fwd<128, 128, 2, 2>(p, vec, st);
     if (p.Cout > 32) {
         const long tiles_mid = (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
