@@ -48,8 +48,8 @@ class ConvTimer(object):
         def call(name, *args):
             if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_wgrad'):
                 if name == 'mmseg_conv2d_fwd':
-                    (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[6:16]
-                    transposed = args[20]
+                    (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[7:17]
+                    transposed = args[21]
                     # algorithmic FLOPs: a fractionally-strided (data-gradient) launch only has the taps of the strided
                     # forward convolution it differentiates, i.e. B*H*W (its INPUT pixels) x KH*KW x Cin x Cout
                     pix = B * H * W if transposed else B * Ho * Wo

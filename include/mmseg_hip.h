@@ -41,9 +41,14 @@ extern "C" {
  * transposed=1 selects the fractionally-strided gather used for the data gradient of a strided convolution
  * (tap valid iff (ho + kh - pad) % stride == 0).  y2/nsplit1: optional channel-split of the output
  * (channels [0,nsplit1) -> y, the rest -> y2), used for the data gradient of a two-input convolution. */
-int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* bias, float* y, float* y2,
+int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, float* y, float* y2,
                      int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                      int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, void* stream);
+/* fast path (Cin % 32 == 0, not transposed): K tiles lie inside one tap, gather by buffer loads, weights read from
+ * `wt` = the kernel re-laid out as [Cout][K] by mmseg_conv2d_wprep (mode 0 forward, mode 1 data gradient incl. the
+ * spatial flip); pass wt = NULL to force the generic kernel. */
+int mmseg_conv2d_fast_path(int C1, int C2, int Cout, int transposed);
+int mmseg_conv2d_wprep(const float* w, float* out, int KH, int KW, int Cin, int Cout, int mode, void* stream);
 long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 /* dW[KH,KW,Cin,Cout] = sum over output pixels of im2col(x)^T * dy ; ws: mmseg_conv2d_wgrad_workspace floats */
 int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,

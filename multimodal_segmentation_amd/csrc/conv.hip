@@ -25,6 +25,7 @@ struct ConvParams {
     const float* x1;
     const float* x2;
     const float* w;
+    const float* wt;    // fast path only: the same kernel as [Cout][K] (K-contiguous rows), see mmseg_conv2d_wprep
     const float* bias;
     float* y;
     float* y2;      // second output for channel-split epilogue (dgrad of a concat conv) or nullptr
@@ -278,9 +279,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_RPP = NT / 8, A_F4 = BM / A_RPP;
-    constexpr int BF4_PER_ROW = BN / 4, B_RPP = NT / BF4_PER_ROW, B_F4 = (BK + B_RPP - 1) / B_RPP;
-    constexpr int BS_LD = BN + 4;
-    constexpr int A_SZ = BM * AS_LD, B_SZ = BK * BS_LD;
+    constexpr int B_F4 = (BN + A_RPP - 1) / A_RPP;       // weight rows (output channels) are staged exactly like pixel rows
+    constexpr int A_SZ = BM * AS_LD, B_SZ = BN * AS_LD;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
     float* As = smem;
@@ -291,12 +291,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
     const int li = lane & 31, lh = lane >> 5;
     const int ntn = (p.Cout + BN - 1) / BN;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (lb / ntn) * BM, n0 = (lb % ntn) * BN;
+    const int mt = lb / ntn, n0 = (lb % ntn) * BN;
+    // 2-D pixel tiles (TH x 16) when the output plane divides evenly: the 9 taps of a tile then re-read an L1-sized
+    // halo patch instead of 9 disjoint row segments; otherwise BM consecutive pixels in raster order
+    constexpr int TH = BM / 16;
+    const bool tile2d = (p.Wo % 16 == 0) && (p.Ho % TH == 0);
+    const int tpr = tile2d ? p.Wo / 16 : 1, tpi = tile2d ? (p.Ho / TH) * tpr : 1;
+    const int t_b = tile2d ? mt / tpi : 0, t_r = tile2d ? mt - t_b * tpi : 0;
+    const int t_y0 = tile2d ? (t_r / tpr) * TH : 0, t_x0 = tile2d ? (t_r % tpr) * 16 : 0;
+    const int m0 = mt * BM;
+    auto row_to_m = [&](int row) -> int {
+        return tile2d ? (t_b * p.Ho + t_y0 + (row >> 4)) * p.Wo + t_x0 + (row & 15) : m0 + row;
+    };
 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
                                                                         p.C2 ? p.B * p.H * p.W * p.C2 * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.K * p.Cout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.K * p.Cout * 4, 0x00020000);
 
     // ---- per-thread row state: element offsets of (b, hb, wb, 4*kc) in x1 / x2 ------------------------------
     const int kc = tid & 7, ar0 = tid >> 3;
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int j = 0; j < A_F4; ++j) {
-        const int m = m0 + ar0 + j * A_RPP;
+        const int m = row_to_m(ar0 + j * A_RPP);
         if (m < p.M) {
             const int b = m / HoWo, r = m - b * HoWo;
             const int ho = r / p.Wo, wo = r - ho * p.Wo;
@@ -318,14 +329,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
     }
     const int Cin = p.C1 + p.C2;
     int s_c0 = 0, s_kh = 0, s_kw = 0;          // wave-uniform position of the next K tile: channel base, tap
-    const int b_nc = tid % BF4_PER_ROW, b_r0 = tid / BF4_PER_ROW;
-    const int b_n = n0 + 4 * b_nc;
-    const int b_off0 = (b_n < p.Cout) ? (b_r0 * p.Cout + b_n) * 4 : BUF_OOB;
-    int b_koff = 0;                            // byte offset of the K tile's first weight row
+    int b_o[B_F4];                             // element offset of (n, 4*kc) in wt, or -1 for rows beyond Cout / BN
+#pragma unroll
+    for (int j = 0; j < B_F4; ++j) {
+        const int row = ar0 + j * A_RPP, n = n0 + row;
+        b_o[j] = (row < BN && n < p.Cout) ? n * p.K + 4 * kc : -1;
+    }
 
     f32x4 ra[A_F4], rb[B_F4];
     auto load_tile = [&]() {
         const int kh = s_kh, kw = s_kw;
+        const int b_koff = (kh * p.KW + kw) * Cin + s_c0;                  // first K column of the tile
         if (s_c0 < p.C1) {
             if (p.ups) {
 #pragma unroll
@@ -354,15 +368,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) {
-            const int kr = j * B_RPP;           // b_r0 already folded into b_off0
-            rb[j] = (b_r0 + kr < BK) ? buf_load4(rw, b_off0 == BUF_OOB ? BUF_OOB : b_off0 + b_koff + kr * p.Cout * 4)
-                                     : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        // advance the uniform K position by one tile
-        b_koff += BK * p.Cout * 4;
-        s_c0 += BK;
-        if (s_c0 >= Cin) { s_c0 = 0; if (++s_kw == p.KW) { s_kw = 0; ++s_kh; } }
+        for (int j = 0; j < B_F4; ++j) rb[j] = buf_load4(rw, b_o[j] >= 0 ? (b_o[j] + b_koff) * 4 : BUF_OOB);
+        // advance the uniform K position by one tile: taps fastest inside a 32-channel chunk, so that consecutive
+        // tiles re-read (shifted) the same cache lines
+        if (++s_kw == p.KW) { s_kw = 0; if (++s_kh == p.KH) { s_kh = 0; s_c0 += BK; } }
     };
     auto store_tile = [&](int buf) {
         float* A = As + buf * A_SZ;
@@ -372,8 +381,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
             *reinterpret_cast<f32x4*>(&A[(ar0 + j * A_RPP) * AS_LD + 4 * kc]) = ra[j];
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
-            const int kr = b_r0 + j * B_RPP;
-            if (kr < BK) *reinterpret_cast<f32x4*>(&Bt[kr * BS_LD + 4 * b_nc]) = rb[j];
+            const int row = ar0 + j * A_RPP;
+            if (row < BN) *reinterpret_cast<f32x4*>(&Bt[row * AS_LD + 4 * kc]) = rb[j];
         }
     };
 
@@ -398,21 +407,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
         const float* Bt = Bs + cur * B_SZ;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 a[TM];
+            f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 a[i] = *reinterpret_cast<const f32x4*>(&A[(a_row + i * 32) * AS_LD + 8 * q + 4 * lh]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float b[TN];
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(&Bt[(b_col + j * 32) * AS_LD + 8 * q + 4 * lh]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = Bt[(8 * q + 4 * lh + t) * BS_LD + b_col + j * 32];
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nkt) store_tile(cur ^ 1);  // the other buffer was last read one iteration ago (barrier below)
         __syncthreads();
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = row_to_m(wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
                 if (m >= p.M) continue;
                 const float v = act_apply(acc[i][j][r] + bv, p.act, p.alpha);
                 if (p.y2 == nullptr) p.y[(size_t)m * p.Cout + n] = v;
@@ -461,7 +469,7 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     const bool vec = (p.C1 % 4 == 0) && (p.C2 % 4 == 0) && aligned16(p.x1) && (p.C2 == 0 || aligned16(p.x2));
     const long tiles_big = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const long lim = (1L << 31) - 64;
-    const bool fast = vec && !p.transposed && (p.C1 % 32 == 0) && (p.C2 % 32 == 0) && (p.Cout % 4 == 0) && aligned16(p.w) &&
+    const bool fast = p.wt != nullptr && aligned16(p.wt) && vec && !p.transposed && (p.C1 % 32 == 0) && (p.C2 % 32 == 0) && (p.Cout % 4 == 0) && aligned16(p.w) &&
                       (long)p.B * p.H1 * p.W1 * p.C1 * 4 < lim && (long)p.B * p.H * p.W * p.C2 * 4 < lim &&
                       (long)p.K * p.Cout * 4 < lim;
     if (fast) {
@@ -643,6 +651,154 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+// ---- wgrad fast path: buffer-load gather (each lane keeps ONE filter tap / channel quad for the whole launch, only its
+// pixel advances), hardware zero fill for padding taps / pixel tails, double-buffered LDS, one barrier per 32 pixels.
+template <int BKT, int BNT, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradParams q) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BKT / WM / 32, TN = BNT / WN / 32;
+    constexpr int PT = 32;
+    constexpr int AF4_PER_ROW = BKT / 4, A_RPP = NT / AF4_PER_ROW, A_F4 = (PT + A_RPP - 1) / A_RPP;
+    constexpr int DF4_PER_ROW = BNT / 4, D_RPP = NT / DF4_PER_ROW, D_F4 = (PT + D_RPP - 1) / D_RPP;
+    constexpr int A_SZ = PT * BKT, D_SZ = PT * BNT;
+    const ConvParams& p = q.c;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + D_SZ)];
+    float* Ap = smem;
+    float* Dp = smem + 2 * A_SZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int k0 = blockIdx.x * BKT, n0 = blockIdx.y * BNT;
+    const int pbeg = blockIdx.z * q.chunk;
+    const int pend = min(p.M, pbeg + q.chunk);
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
+                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)q.dy, 0, p.M * p.Cout * 4, 0x00020000);
+
+    // this lane's 4 consecutive k: fixed tap and channel quad
+    const int a_kc = tid % AF4_PER_ROW, a_r0 = tid / AF4_PER_ROW;
+    const int a_k = k0 + 4 * a_kc;
+    const int Cin = p.C1 + p.C2;
+    const bool k_ok = a_k < p.K;
+    const int a_tap = k_ok ? a_k / Cin : 0, a_c = k_ok ? a_k - a_tap * Cin : 0;
+    const int a_kh = a_tap / p.KW, a_kw = a_tap - a_kh * p.KW;
+    const bool from1 = a_c < p.C1;
+    const int a_cs = from1 ? a_c : a_c - p.C1;
+    int r_b[A_F4], r_ho[A_F4], r_wo[A_F4];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) {
+        const int m = pbeg + a_r0 + j * A_RPP;
+        const int b = m / HoWo, r = m - b * HoWo;
+        r_b[j] = b; r_ho[j] = r / p.Wo; r_wo[j] = r - r_ho[j] * p.Wo;
+    }
+    const int d_nc = tid % DF4_PER_ROW, d_r0 = tid / DF4_PER_ROW;
+    const int d_n = n0 + 4 * d_nc;
+    const bool d_ok = d_n < p.Cout;
+
+    f32x4 ra[A_F4], rd4[D_F4];
+    auto load_stage = [&](int ps) {
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int pr = a_r0 + j * A_RPP;
+            const int hi = r_ho[j] * p.stride - p.pad_h + a_kh, wi = r_wo[j] * p.stride - p.pad_w + a_kw;
+            const bool ok = k_ok && pr < PT && ps + pr < pend && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            int off;
+            if (from1) off = p.ups ? ((r_b[j] * p.H1 + (hi >> 1)) * p.W1 + (wi >> 1)) * p.C1 + a_cs
+                                   : ((r_b[j] * p.H + hi) * p.W + wi) * p.C1 + a_cs;
+            else off = ((r_b[j] * p.H + hi) * p.W + wi) * p.C2 + a_cs;
+            // descriptors must stay wave-uniform: with two inputs issue both loads, the unselected one out of range (zeros)
+            if (p.C2 == 0) ra[j] = buf_load4(r1, ok ? off * 4 : BUF_OOB);
+            else ra[j] = buf_load4(r1, (ok && from1) ? off * 4 : BUF_OOB) + buf_load4(r2, (ok && !from1) ? off * 4 : BUF_OOB);
+            r_wo[j] += PT;
+            while (r_wo[j] >= p.Wo) { r_wo[j] -= p.Wo; if (++r_ho[j] >= p.Ho) { r_ho[j] = 0; ++r_b[j]; } }
+        }
+#pragma unroll
+        for (int j = 0; j < D_F4; ++j) {
+            const int pr = d_r0 + j * D_RPP;
+            const int m = ps + pr;
+            rd4[j] = buf_load4(rd, (d_ok && pr < PT && m < pend) ? (m * p.Cout + d_n) * 4 : BUF_OOB);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float* A = Ap + buf * A_SZ;
+        float* D = Dp + buf * D_SZ;
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            const int pr = a_r0 + j * A_RPP;
+            if (pr < PT) *reinterpret_cast<f32x4*>(&A[pr * BKT + 4 * a_kc]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D_F4; ++j) {
+            const int pr = d_r0 + j * D_RPP;
+            if (pr < PT) *reinterpret_cast<f32x4*>(&D[pr * BNT + 4 * d_nc]) = rd4[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (pbeg < pend) {
+        load_stage(pbeg);
+        store_stage(0);
+        __syncthreads();
+        const int a_col = wm * (BKT / WM) + li, b_col = wn * (BNT / WN) + li;
+        int cur = 0;
+        for (int ps = pbeg; ps < pend; ps += PT) {
+            const bool more = ps + PT < pend;
+            if (more) load_stage(ps + PT);
+            const float* A = Ap + cur * A_SZ;
+            const float* D = Dp + cur * D_SZ;
+#pragma unroll
+            for (int s = 0; s < PT / 2; ++s) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = A[(2 * s + lh) * BKT + a_col + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = D[(2 * s + lh) * BNT + b_col + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_stage(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    float* out = q.ws + (size_t)blockIdx.z * p.K * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BNT / WN) + j * 32 + li;
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * (BKT / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < p.K) out[(size_t)k * p.Cout + n] = acc[i][j][r];
+            }
+    }
+}
+
+template <int BKT, int BNT, int WM, int WN>
+static int launch_wgrad_fast(const WgradParams& q, int S, hipStream_t st) {
+    dim3 grid((q.c.K + BKT - 1) / BKT, (q.c.Cout + BNT - 1) / BNT, S), block(WM * WN * 64);
+    hipLaunchKernelGGL((conv_wgrad_fast_kernel<BKT, BNT, WM, WN>), grid, block, 0, st, q);
+    return MMSEG_CHECK_LAUNCH();
+}
+
 template <int BKT, int BNT, int WM, int WN>
 static int launch_wgrad(const WgradParams& q, int S, bool vec, hipStream_t st) {
     dim3 grid((q.c.K + BKT - 1) / BKT, (q.c.Cout + BNT - 1) / BNT, S), block(WM * WN * 64);
@@ -670,14 +826,32 @@ __global__ void wflip_kernel(const float* __restrict__ w, float* __restrict__ wt
     }
 }
 
+// weight re-layouts for the fast path: out[n][tap'][c] with n the GEMM column (output channel of the launch)
+//   mode 0 (forward)      : out[co][tap][ci] = w[tap][ci][co]
+//   mode 1 (data gradient): out[ci][tap][co] = w[ntaps-1-tap][ci][co]
+__global__ void wprep_kernel(const float* __restrict__ w, float* __restrict__ out, int ntaps, int Cin, int Cout, int mode) {
+    const long n = (long)ntaps * Cin * Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        if (mode == 0) {
+            const int ci = i % Cin; long r = i / Cin;
+            const int tap = r % ntaps; const int co = r / ntaps;
+            out[i] = w[((long)tap * Cin + ci) * Cout + co];
+        } else {
+            const int co = i % Cout; long r = i / Cout;
+            const int tap = r % ntaps; const int ci = r / ntaps;
+            out[i] = w[((long)(ntaps - 1 - tap) * Cin + ci) * Cout + co];
+        }
+    }
+}
+
 extern "C" {
 
 // Geometry arrays are plain ints so the ABI stays free of C++ types (see include/mmseg_hip.h).
-int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* bias, float* y, float* y2,
+int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, float* y, float* y2,
                      int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                      int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, void* stream) {
     ConvParams p;
-    p.x1 = x1; p.x2 = x2; p.w = w; p.bias = bias; p.y = y; p.y2 = y2;
+    p.x1 = x1; p.x2 = x2; p.w = w; p.wt = wt; p.bias = bias; p.y = y; p.y2 = y2;
     p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
     p.H1 = ups ? H / 2 : H; p.W1 = ups ? W / 2 : W;
     p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
@@ -705,7 +879,7 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
                        int pad_h, int pad_w, int ups, void* stream) {
     WgradParams q;
     ConvParams& p = q.c;
-    p.x1 = x1; p.x2 = x2; p.w = nullptr; p.bias = nullptr; p.y = nullptr; p.y2 = nullptr;
+    p.x1 = x1; p.x2 = x2; p.w = nullptr; p.wt = nullptr; p.bias = nullptr; p.y = nullptr; p.y2 = nullptr;
     p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
     p.H1 = ups ? H / 2 : H; p.W1 = ups ? W / 2 : W;
     p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
@@ -722,7 +896,13 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (C1 % 4 == 0) && (C2 % 4 == 0) && aligned16(x1) && (C2 == 0 || aligned16(x2));
     int rc;
-    if (Cout > 32) rc = launch_wgrad<128, 64, 2, 2>(q, S, vec, st);
+    const long lim = (1L << 31) - 64;
+    const bool fast = vec && (Cout % 4 == 0) && aligned16(dy) && (long)B * p.H1 * p.W1 * C1 * 4 < lim &&
+                      (long)B * H * W * C2 * 4 < lim && (long)p.M * Cout * 4 < lim;
+    if (fast && Cout > 64) rc = launch_wgrad_fast<128, 128, 2, 2>(q, S, st);
+    else if (fast && Cout > 32) rc = launch_wgrad_fast<128, 64, 2, 2>(q, S, st);
+    else if (fast) rc = launch_wgrad_fast<128, 32, 4, 1>(q, S, st);
+    else if (Cout > 32) rc = launch_wgrad<128, 64, 2, 2>(q, S, vec, st);
     else rc = launch_wgrad<128, 32, 4, 1>(q, S, vec, st);
     if (rc != 0 || S == 1) return rc;
     const long n4 = (KN + 3) / 4;
@@ -730,6 +910,18 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     return MMSEG_CHECK_LAUNCH();
 }
 
+// 1 when mmseg_conv2d_fwd takes the fast path for this geometry (then it wants `wt` from mmseg_conv2d_wprep)
+int mmseg_conv2d_fast_path(int C1, int C2, int Cout, int transposed) {
+    return (!transposed && C1 % 32 == 0 && C2 % 32 == 0 && Cout % 4 == 0) ? 1 : 0;
+}
+// mode 0: forward layout [Cout][KH*KW][Cin]; mode 1: data-gradient layout [Cin][KH*KW flipped][Cout]
+int mmseg_conv2d_wprep(const float* w, float* out, int KH, int KW, int Cin, int Cout, int mode, void* stream) {
+    const long n = (long)KH * KW * Cin * Cout;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wprep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH * KW, Cin, Cout, mode);
+    return MMSEG_CHECK_LAUNCH();
+}
 int mmseg_conv2d_wflip(const float* w, float* wt, int KH, int KW, int Cin, int Cout, void* stream) {
     if (KH * KW > 65535) return (int)hipErrorInvalidValue;
     dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, KH * KW);

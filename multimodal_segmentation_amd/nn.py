@@ -190,6 +190,7 @@ class Model(object):
             if tuple(w.shape) != p.shape:
                 raise ValueError('weight %s: shape %s != %s' % (p.name, w.shape, p.shape))
             p.data.copy_(torch.from_numpy(w).to(p.data.device))
+        ops.bump_weight_version()
 
     def named_weights(self, prefix=''):
         """name -> numpy array (the oracle's parameter naming)."""

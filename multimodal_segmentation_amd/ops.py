@@ -50,18 +50,39 @@ def _conv_geometry(H, W, KH, KW, stride, padding):
     raise ValueError(padding)
 
 
-def _conv_fwd_raw(x1, x2, w, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, transposed,
+_weight_version = [0]
+_wprep_cache = {}
+
+
+def bump_weight_version():
+    """Invalidate the cached weight re-layouts (called whenever weights change: optimiser step, set_weights)."""
+    _weight_version[0] += 1
+
+
+def _wprep(w, KH, KW, Cin, Cout, mode):
+    """Cached [N][K] re-layout of a conv kernel for the fast path (mode 0: forward, 1: data gradient)."""
+    key = (w.data_ptr(), mode)
+    ent = _wprep_cache.get(key)
+    if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == w.numel():
+        return ent[1]
+    out = ent[1] if (ent is not None and ent[1].numel() == w.numel()) else torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    N.call('mmseg_conv2d_wprep', w, out, KH, KW, Cin, Cout, mode)
+    _wprep_cache[key] = (_weight_version[0], out)
+    return out
+
+
+def _conv_fwd_raw(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, transposed,
                   act, alpha, nsplit1):
     # host-side shape checks: the kernel trusts these numbers
     assert x1.numel() == B * (H >> ups) * (W >> ups) * C1, 'x1 shape/geometry mismatch'
     assert (x2 is None and C2 == 0) or x2.numel() == B * H * W * C2, 'x2 shape/geometry mismatch'
-    assert w.numel() == KH * KW * (C1 + C2) * Cout, 'kernel shape mismatch'
+    assert (w if w is not None else wt).numel() == KH * KW * (C1 + C2) * Cout, 'kernel shape mismatch'
     assert bias is None or bias.numel() == Cout
     if y2 is None:
         assert y.numel() == B * Ho * Wo * Cout
     else:
         assert y.numel() == B * Ho * Wo * nsplit1 and y2.numel() == B * Ho * Wo * (Cout - nsplit1)
-    N.call('mmseg_conv2d_fwd', x1, x2, w, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw,
+    N.call('mmseg_conv2d_fwd', x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw,
            ups, transposed, act, float(alpha), nsplit1)
 
 
@@ -87,7 +108,8 @@ class _Conv2d(torch.autograd.Function):
         assert Cin == C1 + C2, 'kernel expects %d input channels, got %d' % (Cin, C1 + C2)
         Ho, Wo, ph, pw = _conv_geometry(H, W, KH, KW, stride, padding)
         y = _new((B, Ho, Wo, Cout), x1)
-        _conv_fwd_raw(x1, x2, w, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,
+        wt = _wprep(w, KH, KW, Cin, Cout, 0) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
+        _conv_fwd_raw(x1, x2, w, wt, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,
                       ACT[act], alpha, 0)
         ctx.geom = (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), ACT[act], alpha)
         ctx.wgrad, ctx.bgrad = wgrad, bgrad
@@ -121,13 +143,17 @@ class _Conv2d(torch.autograd.Function):
             _accumulate(ctx.wgrad.view(-1), dw)
         if need_x1 or (x2 is not None and need_x2):
             Cin = C1 + C2
-            wt = _ws('wflip', w.numel(), dy.device)[:w.numel()]
-            N.call('mmseg_conv2d_wflip', w, wt, KH, KW, Cin, Cout)
+            tr = 1 if stride > 1 else 0
+            if N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, tr):
+                wf, wt = None, _wprep(w, KH, KW, Cin, Cout, 1)     # [Cin][flipped taps][Cout]
+            else:
+                wf, wt = _ws('wflip', w.numel(), dy.device)[:w.numel()], None
+                N.call('mmseg_conv2d_wflip', w, wf, KH, KW, Cin, Cout)
             d1 = _new((B, H, W, C1), dy)
             d2 = _new((B, H, W, C2), dy) if C2 else None
             # data gradient = convolution of g with the flipped kernel; fractionally strided when stride > 1
-            _conv_fwd_raw(g, None, wt, None, d1, d2, B, Ho, Wo, Cout, 0, H, W, Cin, KH, KW, stride, KH - 1 - ph,
-                          KW - 1 - pw, 0, 1 if stride > 1 else 0, 0, 0.0, C1 if C2 else 0)
+            _conv_fwd_raw(g, None, wf, wt, None, d1, d2, B, Ho, Wo, Cout, 0, H, W, Cin, KH, KW, stride, KH - 1 - ph,
+                          KW - 1 - pw, 0, tr, 0, 0.0, C1 if C2 else 0)
             if ups:
                 dx1 = _new((B, H // 2, W // 2, C1), dy)
                 N.call('mmseg_upsample2_bwd', d1, dx1, B, H // 2, W // 2, C1)
@@ -637,6 +663,7 @@ def adam_step(p, g, m, v, lr_t, beta_1=0.9, beta_2=0.999, eps=1e-7):
     """Keras 2.1.6 Adam over flat arenas (p, g, m, v: 1-D views of equal length)."""
     assert p.numel() == g.numel() == m.numel() == v.numel()
     N.call('mmseg_adam', p, g, m, v, p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps))
+    bump_weight_version()
 
 
 def fill_(t, value):

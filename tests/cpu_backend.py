@@ -43,7 +43,17 @@ def _logical_input(x1, x2, B, H, W, C1, C2, ups):
     return a
 
 
-def conv2d_fwd(x1, x2, w, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, transposed, act,
+def conv2d_fast_path(C1, C2, Cout, transposed):
+    return 0
+
+
+def conv2d_wprep(w, out, KH, KW, Cin, Cout, mode):
+    wk = w.reshape(KH * KW, Cin, Cout)
+    r = wk.permute(2, 0, 1) if mode == 0 else torch.flip(wk, (0,)).permute(1, 0, 2)
+    out.copy_(r.reshape(-1)); return 0
+
+
+def conv2d_fwd(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, transposed, act,
                alpha, nsplit1):
     xin = _logical_input(x1, x2, B, H, W, C1, C2, ups).permute(0, 3, 1, 2)
     wk = w.reshape(KH, KW, C1 + C2, Cout).permute(3, 2, 0, 1)

@@ -20,7 +20,7 @@ def test_header_parses_and_library_exports_every_symbol():
         assert hasattr(lib, name), name
     # prototypes: every launcher ends with the stream parameter
     ret, types = protos['mmseg_conv2d_fwd']
-    assert ret == 'int' and types[-1] == 'void*' and len(types) == 25
+    assert ret == "int" and types[-1] == "void*" and len(types) == 26
 
 
 def test_workspace_queries_run_without_gpu():

@@ -45,9 +45,13 @@ def main():
         ws = torch.empty(max(need, 1), device=dev)
         p = k // 2
         flops = 2.0 * B * H * H * Cin * Cout * k * k
-        t_f = timeit(lambda: N.call('mmseg_conv2d_fwd', x, None, w, b, y, None, B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0, 0, 1, 0.0, 0))
+        wp = torch.empty_like(wt)
+        N.call('mmseg_conv2d_wprep', w, wp, k, k, Cin, Cout, 0)
+        t_f = timeit(lambda: N.call('mmseg_conv2d_fwd', x, None, w, wp, b, y, None, B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0, 0, 1, 0.0, 0))
         N.call('mmseg_conv2d_wflip', w, wt, k, k, Cin, Cout)
-        t_d = timeit(lambda: N.call('mmseg_conv2d_fwd', y, None, wt, None, dx, None, B, H, H, Cout, 0, H, H, Cin, k, k, 1, p, p, 0, 0, 0, 0.0, 0))
+        wp2 = torch.empty_like(wt)
+        N.call('mmseg_conv2d_wprep', w, wp2, k, k, Cin, Cout, 1)
+        t_d = timeit(lambda: N.call('mmseg_conv2d_fwd', y, None, wt, wp2, None, dx, None, B, H, H, Cout, 0, H, H, Cin, k, k, 1, p, p, 0, 0, 0, 0.0, 0))
         t_w = timeit(lambda: N.call('mmseg_conv2d_wgrad', x, None, y, dw, ws, ws.numel(), B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0))
         print('%4d^2 %4d->%4d k%d      %6.1f %5.2f %6.1f %5.2f %6.1f %5.2f' %
               (H, Cin, Cout, k, flops / t_f / 1e9, t_f, flops / t_d / 1e9, t_d, flops / t_w / 1e9, t_w))
