@@ -462,10 +462,69 @@ static int launch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
     return MMSEG_CHECK_LAUNCH();
 }
 
+// =====================================================================================
+// Direct convolution for the tiny-channel layers of the FiLM decoder (3x3, 8 -> 8, stride 1, 'same'): arithmetic
+// intensity ~18 FLOP/B, i.e. HBM-bound -- an MFMA tile would be >= 75 % padding.  One thread per output pixel, the 576
+// weights come through scalar loads (wave-uniform addresses), inputs as 16-byte loads of the 9 taps (L1/L2 hits).
+// Replaces Conv2D(8, 3, padding='same') of model_components/decoder.py:45-48,58 and its data gradient.
+// =====================================================================================
+typedef unsigned int u32x4d __attribute__((ext_vector_type(4)));
+template <int CIN, int COUT, int KS>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int B, int H, int W, int pad, int act, float alpha) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long npix = (long)B * H * W;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(npix * CIN * 4), 0x00020000);
+    const bool live = idx < npix;
+    const int wq = idx % W; long r = idx / W;
+    const int hq = r % H; const int b = r / H;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+    // one filter tap per (NOT unrolled) iteration: its CIN*COUT weights fit the scalar register file (a fully unrolled
+    // body would need 576 SGPRs and spill them through v_readlane); the tap's inputs are fetched branch-free (padding
+    // taps get an out-of-range offset and read as zeros); the small register footprint gives 8 waves/SIMD to hide
+    // the load latency
+#pragma unroll 1
+    for (int t = 0; t < KS * KS; ++t) {
+        const int kh = t / KS, kw = t - kh * KS;
+        const int hi = hq + kh - pad, wi = wq + kw - pad;
+        const bool ok = live && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const int off = (((b * H + hi) * W + wi) * CIN) * 4;
+        f32x4 xv[CIN / 4];
+#pragma unroll
+        for (int q = 0; q < CIN / 4; ++q)
+            xv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off + 16 * q : 0x7ffffff0, 0, 0));
+        const float* wt = w + t * CIN * COUT;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+                acc[co] = fmaf(xv[ci >> 2][ci & 3], wt[ci * COUT + co], acc[co]);
+    }
+    if (!live) return;
+    f32x4* dst = reinterpret_cast<f32x4*>(y + idx * COUT);
+#pragma unroll
+    for (int q = 0; q < COUT / 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(acc[4 * q + e], act, alpha);
+        dst[q] = v;
+    }
+}
+
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (p.M <= 0 || p.Cout <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
+    if (p.C1 == 8 && p.C2 == 0 && p.Cout == 8 && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.transposed && !p.ups &&
+        p.Ho == p.H && p.Wo == p.W && p.pad_h == 1 && p.pad_w == 1 && p.y2 == nullptr && p.w != nullptr &&
+        aligned16(p.x1) && aligned16(p.y)) {
+        hipLaunchKernelGGL((conv_direct_kernel<8, 8, 3>), dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st,
+                           p.x1, p.w, p.bias, p.y, p.B, p.H, p.W, 1, p.act, p.alpha);
+        return MMSEG_CHECK_LAUNCH();
+    }
     const bool vec = (p.C1 % 4 == 0) && (p.C2 % 4 == 0) && aligned16(p.x1) && (p.C2 == 0 || aligned16(p.x2));
     const long tiles_big = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const long lim = (1L << 31) - 64;
