@@ -46,8 +46,13 @@ class ConvTimer(object):
         timer = self
 
         def call(name, *args):
-            if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_wgrad'):
-                if name == 'mmseg_conv2d_fwd':
+            if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_wgrad', 'mmseg_conv2d_dgrad_parity'):
+                if name == 'mmseg_conv2d_dgrad_parity':
+                    (B, Ho, Wo, Cout, H, W, Cin, TH, TW, stride, ph, pw) = args[3:15]
+                    hs, ws = (H - ph + stride - 1) // stride, (W - pw + stride - 1) // stride
+                    flops = 2.0 * B * hs * ws * Cin * TH * TW * Cout     # exact taps of this parity class
+                    kind = 'conv_fwd_kernel'
+                elif name == 'mmseg_conv2d_fwd':
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[7:17]
                     transposed = args[21]
                     # algorithmic FLOPs: a fractionally-strided (data-gradient) launch only has the taps of the strided

@@ -49,6 +49,13 @@ int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const flo
  * spatial flip); pass wt = NULL to force the generic kernel. */
 int mmseg_conv2d_fast_path(int C1, int C2, int Cout, int transposed);
 int mmseg_conv2d_wprep(const float* w, float* out, int KH, int KW, int Cin, int Cout, int mode, void* stream);
+/* data gradient of a STRIDED convolution, one launch per parity class (ph, pw) of the input pixels: only the taps
+ * kh = ph + s*a, kw = pw + s*b contribute, so each class is a stride-1 convolution over dy with a small sub-kernel and a
+ * strided store -- no multiplications by the zeros of a dilated gradient.  wt from mmseg_conv2d_wprep_parity. */
+int mmseg_conv2d_parity_taps(int K, int stride, int p);
+int mmseg_conv2d_wprep_parity(const float* w, float* out, int KH, int KW, int Cin, int Cout, int stride, int ph, int pw, void* stream);
+int mmseg_conv2d_dgrad_parity(const float* dy, const float* wt, float* dx, int B, int Ho, int Wo, int Cout, int H, int W, int Cin,
+                              int TH, int TW, int stride, int ph, int pw, void* stream);
 long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 /* dW[KH,KW,Cin,Cout] = sum over output pixels of im2col(x)^T * dy ; ws: mmseg_conv2d_wgrad_workspace floats */
 int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,

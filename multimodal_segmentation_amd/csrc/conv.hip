@@ -40,6 +40,9 @@ struct ConvParams {
     float alpha;
     int M, K;
     int nsplit1;    // channel split point of the epilogue (Cout1) when y2 != nullptr
+    // output pixel mapping (fast path): launch pixel (b, ho, wo) is stored at (b, ho*osh + ooh, wo*osw + oow) of a
+    // [B, oH, oW, Cout] tensor.  Identity unless the launch is one parity class of a strided data gradient.
+    int oH, oW, osh, osw, ooh, oow;
 };
 
 #define BK 32
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
         }
     }
     const int Cin = p.C1 + p.C2;
+    const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
     int s_c0 = 0, s_kh = 0, s_kw = 0;          // wave-uniform position of the next K tile: channel base, tap
     int b_o[B_F4];                             // element offset of (n, 4*kc) in wt, or -1 for rows beyond Cout / BN
 #pragma unroll
@@ -435,8 +439,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = row_to_m(wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+                int m = row_to_m(wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
                 if (m >= p.M) continue;
+                if (omap) {
+                    const int ob = m / HoWo, orr = m - ob * HoWo;
+                    const int oh = orr / p.Wo, ow = orr - oh * p.Wo;
+                    m = (ob * p.oH + oh * p.osh + p.ooh) * p.oW + ow * p.osw + p.oow;
+                }
                 const float v = act_apply(acc[i][j][r] + bv, p.act, p.alpha);
                 if (p.y2 == nullptr) p.y[(size_t)m * p.Cout + n] = v;
                 else if (n < p.nsplit1) p.y[(size_t)m * p.nsplit1 + n] = v;
@@ -519,7 +528,7 @@ static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (p.M <= 0 || p.Cout <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
     if (p.C1 == 8 && p.C2 == 0 && p.Cout == 8 && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.transposed && !p.ups &&
-        p.Ho == p.H && p.Wo == p.W && p.pad_h == 1 && p.pad_w == 1 && p.y2 == nullptr && p.w != nullptr &&
+        p.Ho == p.H && p.Wo == p.W && p.pad_h == 1 && p.pad_w == 1 && p.y2 == nullptr && p.w != nullptr && p.osh == 1 &&
         aligned16(p.x1) && aligned16(p.y)) {
         hipLaunchKernelGGL((conv_direct_kernel<8, 8, 3>), dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st,
                            p.x1, p.w, p.bias, p.y, p.B, p.H, p.W, 1, p.act, p.alpha);
@@ -531,6 +540,8 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     const bool fast = p.wt != nullptr && aligned16(p.wt) && vec && !p.transposed && (p.C1 % 32 == 0) && (p.C2 % 32 == 0) && (p.Cout % 4 == 0) && aligned16(p.w) &&
                       (long)p.B * p.H1 * p.W1 * p.C1 * 4 < lim && (long)p.B * p.H * p.W * p.C2 * 4 < lim &&
                       (long)p.K * p.Cout * 4 < lim;
+    const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
+    if (omap && !fast) return (int)hipErrorInvalidValue;     // strided output mapping exists on the fast path only
     if (fast) {
         if (p.Cout > 64 && tiles_big >= 384) return launch_fast<128, 128, 2, 2>(p, st);
         if (p.Cout > 32) {
@@ -903,13 +914,28 @@ __global__ void wprep_kernel(const float* __restrict__ w, float* __restrict__ ou
     }
 }
 
+// sub-kernel of parity class (ph, pw): out[ci][(th, tw)][co] = w[ph + s*(TH-1-th)][pw + s*(TW-1-tw)][ci][co]
+__global__ void wprep_parity_kernel(const float* __restrict__ w, float* __restrict__ out, int KH, int KW, int Cin, int Cout,
+                                    int TH, int TW, int s, int ph, int pw) {
+    const long n = (long)TH * TW * Cin * Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int co = i % Cout; long r = i / Cout;
+        const int tw = r % TW; r /= TW;
+        const int th = r % TH; const int ci = r / TH;
+        const int kh = ph + s * (TH - 1 - th), kw = pw + s * (TW - 1 - tw);
+        out[i] = w[(((long)kh * KW + kw) * Cin + ci) * Cout + co];
+    }
+}
+
 extern "C" {
 
 // Geometry arrays are plain ints so the ABI stays free of C++ types (see include/mmseg_hip.h).
-int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, float* y, float* y2,
-                     int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
-                     int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, void* stream) {
+static int conv2d_fwd_impl(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, float* y, float* y2,
+                           int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                           int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1,
+                           int oH, int oW, int osh, int osw, int ooh, int oow, void* stream) {
     ConvParams p;
+    p.oH = oH; p.oW = oW; p.osh = osh; p.osw = osw; p.ooh = ooh; p.oow = oow;
     p.x1 = x1; p.x2 = x2; p.w = w; p.wt = wt; p.bias = bias; p.y = y; p.y2 = y2;
     p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
     p.H1 = ups ? H / 2 : H; p.W1 = ups ? W / 2 : W;
@@ -919,7 +945,25 @@ int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const flo
     if (ups && ((H & 1) || (W & 1))) return (int)hipErrorInvalidValue;
     if (C2 > 0 && x2 == nullptr) return (int)hipErrorInvalidValue;
     if ((long)B * Ho * Wo >= (1L << 31)) return (int)hipErrorInvalidValue;
+    if (osh < 1 || osw < 1 || (long)(Ho - 1) * osh + ooh >= oH || (long)(Wo - 1) * osw + oow >= oW) return (int)hipErrorInvalidValue;
     return conv_dispatch(p, (hipStream_t)stream);
+}
+int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, float* y, float* y2,
+                     int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                     int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, void* stream) {
+    return conv2d_fwd_impl(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad_h, pad_w, ups,
+                           transposed, act, alpha, nsplit1, Ho, Wo, 1, 1, 0, 0, stream);
+}
+// One parity class (ph, pw) of the data gradient of a stride-s convolution (s = 2), exact taps only:
+//   dx[b, s*i + ph, s*j + pw, :] = sum_{a,b2} dy[b, i - a, j - b2, :] . W[ph + s*a, pw + s*b2, :, :]^T
+// run as a stride-1 convolution over dy with the TH x TW sub-kernel `wt` (mmseg_conv2d_wprep_parity, fast layout) and a
+// strided store into dx [B, H, W, Cin].  Needs Cout % 32 == 0 and Cin % 4 == 0 (mmseg_conv2d_fast_path(Cout,0,Cin,0)).
+int mmseg_conv2d_dgrad_parity(const float* dy, const float* wt, float* dx, int B, int Ho, int Wo, int Cout, int H, int W, int Cin,
+                              int TH, int TW, int stride, int ph, int pw, void* stream) {
+    const int Hs = (H - ph + stride - 1) / stride, Ws = (W - pw + stride - 1) / stride;
+    if (Hs <= 0 || Ws <= 0) return 0;
+    return conv2d_fwd_impl(dy, nullptr, nullptr, wt, nullptr, dx, nullptr, B, Ho, Wo, Cout, 0, Hs, Ws, Cin, TH, TW, 1, TH - 1, TW - 1,
+                           0, 0, 0, 0.f, 0, H, W, stride, stride, ph, pw, stream);
 }
 
 // number of floats of workspace mmseg_conv2d_wgrad needs for this geometry (0: writes dW directly)
@@ -944,6 +988,7 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
     p.pad_h = pad_h; p.pad_w = pad_w; p.ups = ups; p.transposed = 0; p.act = 0; p.alpha = 0.f;
     p.M = B * Ho * Wo; p.K = KH * KW * (C1 + C2); p.nsplit1 = 0;
+    p.oH = Ho; p.oW = Wo; p.osh = 1; p.osw = 1; p.ooh = 0; p.oow = 0;
     if (p.M <= 0 || p.K <= 0 || Cout <= 0) return (int)hipErrorInvalidValue;
     const long need = mmseg_conv2d_wgrad_workspace(B, Ho, Wo, C1 + C2, Cout, KH, KW);
     if (need > ws_floats) return (int)hipErrorInvalidValue;
@@ -979,6 +1024,17 @@ int mmseg_conv2d_wprep(const float* w, float* out, int KH, int KW, int Cin, int 
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wprep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH * KW, Cin, Cout, mode);
+    return MMSEG_CHECK_LAUNCH();
+}
+// taps of parity class p along one axis: kh = p, p + s, ... < K
+int mmseg_conv2d_parity_taps(int K, int stride, int p) { return p < K ? (K - p + stride - 1) / stride : 0; }
+int mmseg_conv2d_wprep_parity(const float* w, float* out, int KH, int KW, int Cin, int Cout, int stride, int ph, int pw, void* stream) {
+    const int TH = mmseg_conv2d_parity_taps(KH, stride, ph), TW = mmseg_conv2d_parity_taps(KW, stride, pw);
+    if (TH == 0 || TW == 0) return 0;
+    const long n = (long)TH * TW * Cin * Cout;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wprep_parity_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH, KW, Cin, Cout, TH, TW, stride, ph, pw);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_conv2d_wflip(const float* w, float* wt, int KH, int KW, int Cin, int Cout, void* stream) {

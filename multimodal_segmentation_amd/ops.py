@@ -71,6 +71,19 @@ def _wprep(w, KH, KW, Cin, Cout, mode):
     return out
 
 
+def _wprep_parity(w, KH, KW, Cin, Cout, stride, ph, pw, ntaps):
+    """Cached sub-kernel of one parity class of a strided convolution's data gradient (fast layout)."""
+    key = (w.data_ptr(), 'parity', stride, ph, pw)
+    n = ntaps * Cin * Cout
+    ent = _wprep_cache.get(key)
+    if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == n:
+        return ent[1]
+    out = ent[1] if (ent is not None and ent[1].numel() == n) else torch.empty(n, dtype=torch.float32, device=w.device)
+    N.call('mmseg_conv2d_wprep_parity', w, out, KH, KW, Cin, Cout, stride, ph, pw)
+    _wprep_cache[key] = (_weight_version[0], out)
+    return out
+
+
 def _conv_fwd_raw(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, transposed,
                   act, alpha, nsplit1):
     # host-side shape checks: the kernel trusts these numbers
@@ -144,16 +157,25 @@ class _Conv2d(torch.autograd.Function):
         if need_x1 or (x2 is not None and need_x2):
             Cin = C1 + C2
             tr = 1 if stride > 1 else 0
-            if N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, tr):
-                wf, wt = None, _wprep(w, KH, KW, Cin, Cout, 1)     # [Cin][flipped taps][Cout]
-            else:
-                wf, wt = _ws('wflip', w.numel(), dy.device)[:w.numel()], None
-                N.call('mmseg_conv2d_wflip', w, wf, KH, KW, Cin, Cout)
             d1 = _new((B, H, W, C1), dy)
             d2 = _new((B, H, W, C2), dy) if C2 else None
-            # data gradient = convolution of g with the flipped kernel; fractionally strided when stride > 1
-            _conv_fwd_raw(g, None, wf, wt, None, d1, d2, B, Ho, Wo, Cout, 0, H, W, Cin, KH, KW, stride, KH - 1 - ph,
-                          KW - 1 - pw, 0, tr, 0, 0.0, C1 if C2 else 0)
+            taps = [[N.call('mmseg_conv2d_parity_taps', k, stride, q) for q in range(stride)] for k in (KH, KW)] if tr else None
+            if tr and C2 == 0 and not ups and N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0) and min(taps[0] + taps[1]) > 0:
+                # strided convolution: one exact stride-1 launch per parity class of the input pixels
+                for qh in range(stride):
+                    for qw in range(stride):
+                        wp = _wprep_parity(w, KH, KW, Cin, Cout, stride, qh, qw, taps[0][qh] * taps[1][qw])
+                        N.call('mmseg_conv2d_dgrad_parity', g, wp, d1, B, Ho, Wo, Cout, H, W, Cin, taps[0][qh], taps[1][qw],
+                               stride, qh, qw)
+            else:
+                if N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, tr):
+                    wf, wt = None, _wprep(w, KH, KW, Cin, Cout, 1)     # [Cin][flipped taps][Cout]
+                else:
+                    wf, wt = _ws('wflip', w.numel(), dy.device)[:w.numel()], None
+                    N.call('mmseg_conv2d_wflip', w, wf, KH, KW, Cin, Cout)
+                # data gradient = convolution of g with the flipped kernel; fractionally strided when stride > 1
+                _conv_fwd_raw(g, None, wf, wt, None, d1, d2, B, Ho, Wo, Cout, 0, H, W, Cin, KH, KW, stride, KH - 1 - ph,
+                              KW - 1 - pw, 0, tr, 0, 0.0, C1 if C2 else 0)
             if ups:
                 dx1 = _new((B, H // 2, W // 2, C1), dy)
                 N.call('mmseg_upsample2_bwd', d1, dx1, B, H // 2, W // 2, C1)

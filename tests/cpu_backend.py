@@ -47,6 +47,10 @@ def conv2d_fast_path(C1, C2, Cout, transposed):
     return 0
 
 
+def conv2d_parity_taps(K, stride, p):
+    return (K - p + stride - 1) // stride if p < K else 0
+
+
 def conv2d_wprep(w, out, KH, KW, Cin, Cout, mode):
     wk = w.reshape(KH * KW, Cin, Cout)
     r = wk.permute(2, 0, 1) if mode == 0 else torch.flip(wk, (0,)).permute(1, 0, 2)
