@@ -283,7 +283,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_RPP = NT / 8, A_F4 = BM / A_RPP;
     constexpr int B_F4 = (BN + A_RPP - 1) / A_RPP;       // weight rows (output channels) are staged exactly like pixel rows
-    constexpr int A_SZ = BM * AS_LD, B_SZ = BN * AS_LD;
+    // LDS tiles: 32 floats per row, NO padding; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7, which makes
+    // both the ds_write_b128 (8 lanes = 8 chunks of one row) and the ds_read_b128 (16-lane groups over distinct rows)
+    // conflict-free and lets 3 blocks of the 128x64 tile share a CU's 160 KB
+    constexpr int LD = BK;
+    constexpr int A_SZ = BM * LD, B_SZ = BN * LD;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
     float* As = smem;
@@ -382,11 +386,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
         float* Bt = Bs + buf * B_SZ;
 #pragma unroll
         for (int j = 0; j < A_F4; ++j)
-            *reinterpret_cast<f32x4*>(&A[(ar0 + j * A_RPP) * AS_LD + 4 * kc]) = ra[j];
+            *reinterpret_cast<f32x4*>(&A[(ar0 + j * A_RPP) * LD + 4 * (kc ^ (((ar0 + j * A_RPP) >> 1) & 7))]) = ra[j];
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) {
             const int row = ar0 + j * A_RPP;
-            if (row < BN) *reinterpret_cast<f32x4*>(&Bt[row * AS_LD + 4 * kc]) = rb[j];
+            if (row < BN) *reinterpret_cast<f32x4*>(&Bt[row * LD + 4 * (kc ^ ((row >> 1) & 7))]) = rb[j];
         }
     };
 
@@ -414,10 +418,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
             f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(&A[(a_row + i * 32) * AS_LD + 8 * q + 4 * lh]);
+                a[i] = *reinterpret_cast<const f32x4*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ (((a_row + i * 32) >> 1) & 7))]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(&Bt[(b_col + j * 32) * AS_LD + 8 * q + 4 * lh]);
+                b[j] = *reinterpret_cast<const f32x4*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ (((b_col + j * 32) >> 1) & 7))]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll

@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Run one convolution shape a few times (for rocprofv3 --pmc): python tools/conv_one.py H Cin Cout [fwd|wgrad]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodal_segmentation_amd import _native as N
+H, Cin, Cout = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+mode = sys.argv[4] if len(sys.argv) > 4 else 'fwd'
+B, k, p = 8, 3, 1
+dev = torch.device('cuda')
+N.load()
+x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(k, k, Cin, Cout, device=dev) * 0.05
+y = torch.empty(B, H, H, Cout, device=dev); wp = torch.empty(w.numel(), device=dev); dw = torch.empty_like(w)
+N.call('mmseg_conv2d_wprep', w, wp, k, k, Cin, Cout, 0)
+need = N.call('mmseg_conv2d_wgrad_workspace', B, H, H, Cin, Cout, k, k); ws = torch.empty(max(need, 1), device=dev)
+for _ in range(5):
+    if mode == 'fwd':
+        N.call('mmseg_conv2d_fwd', x, None, w, wp, None, y, None, B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0, 0, 0, 0.0, 0)
+    else:
+        N.call('mmseg_conv2d_wgrad', x, None, y, dw, ws, ws.numel(), B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0)
+torch.cuda.synchronize()
