@@ -4,10 +4,10 @@
 // models/discriminator.py:32-33, model_components/balancer.py:24-25 of the reference.
 #include "common.hpp"
 
-#define DENSE_KSLICES_MAX 256
+#define DENSE_KSLICES_MAX 1024
 
 static inline int dense_kslices(int K) {
-    int ks = (K + 511) / 512;
+    int ks = (K + 127) / 128;
     if (ks > DENSE_KSLICES_MAX) ks = DENSE_KSLICES_MAX;
     if (ks < 1) ks = 1;
     return ks;
@@ -25,6 +25,7 @@ __global__ void dense_fwd_partial_kernel(const float* __restrict__ x, const floa
 #pragma unroll
     for (int b = 0; b < RB; ++b) acc[b] = 0.f;
     if (n < N) {
+#pragma unroll 4
         for (int k = kbeg + kl; k < kend; k += 4) {
             const float wv = w[(size_t)k * N + n];
 #pragma unroll
@@ -42,14 +43,60 @@ __global__ void dense_fwd_partial_kernel(const float* __restrict__ x, const floa
     }
 }
 
-__global__ void dense_fwd_final_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
-                                       int R, int N, int ks, int act, float alpha) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R * N) return;
+// N <= 4 (discriminator head, K = 373248): lanes run along K so that every lane is useful; block = 256 threads x 8 k each
+template <int RB, int NB>
+__global__ __launch_bounds__(256) void dense_fwd_smalln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ part, int R, int K, int N) {
+    __shared__ float red[17];
+    float acc[RB][NB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[b][n] = 0.f;
+    const int k0 = blockIdx.x * 2048;
+#pragma unroll 4
+    for (int i = 0; i < 8; ++i) {
+        const int k = k0 + i * 256 + threadIdx.x;
+        if (k < K) {
+            float wv[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) wv[n] = n < N ? w[(size_t)k * N + n] : 0.f;
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                if (b < R) {
+                    const float xv = x[(size_t)b * K + k];
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) acc[b][n] += xv * wv[n];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const float t = block_sum(acc[b][n], red);
+            if (threadIdx.x == 0 && b < R && n < N) part[((size_t)blockIdx.x * R + b) * N + n] = t;
+        }
+}
+
+// y[i] = act(bias + sum_s part[s][i]); block 256 = 64 outputs x 4 slice lanes (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void dense_fwd_final_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int R, int N, int ks, int act, float alpha) {
+    __shared__ float sm[256];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     float t = 0.f;
-    for (int s = 0; s < ks; ++s) t += part[(size_t)s * R * N + i];
-    if (bias) t += bias[i % N];
-    y[i] = act_apply(t, act, alpha);
+    if (i < R * N) {
+#pragma unroll 4
+        for (int s = lane; s < ks; s += 4) t += part[(size_t)s * R * N + i];
+    }
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    if (lane == 0 && i < R * N) {
+        t = sm[threadIdx.x] + sm[64 + threadIdx.x] + sm[128 + threadIdx.x] + sm[192 + threadIdx.x];
+        if (bias) t += bias[i % N];
+        y[i] = act_apply(t, act, alpha);
+    }
 }
 
 // dx[b][k] = sum_n dy[b][n] * W[k][n]; 64 rows of W per block staged through LDS in N-chunks of 128
@@ -108,19 +155,34 @@ __global__ void dense_wgrad_kernel(const float* __restrict__ x, const float* __r
 
 extern "C" {
 
-long mmseg_dense_workspace_floats(int R, int K, int N) { return (long)dense_kslices(K) * R * N; }
+long mmseg_dense_workspace_floats(int R, int K, int N) {
+    const long a = (long)dense_kslices(K) * R * N, b = (long)((K + 2047) / 2048) * R * N;
+    return a > b ? a : b;
+}
 
 int mmseg_dense_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int R, int K, int N, int act,
                     float alpha, void* stream) {
     if (R < 1 || R > 32) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
+    if (N <= 4 && R <= 16 && K >= 4096) {
+        const int nb = (K + 2047) / 2048;
+        if (R <= 8) {
+            if (N == 1) hipLaunchKernelGGL((dense_fwd_smalln_kernel<8, 1>), dim3(nb), dim3(256), 0, st, x, w, ws, R, K, N);
+            else hipLaunchKernelGGL((dense_fwd_smalln_kernel<8, 4>), dim3(nb), dim3(256), 0, st, x, w, ws, R, K, N);
+        } else {
+            if (N == 1) hipLaunchKernelGGL((dense_fwd_smalln_kernel<16, 1>), dim3(nb), dim3(256), 0, st, x, w, ws, R, K, N);
+            else hipLaunchKernelGGL((dense_fwd_smalln_kernel<16, 4>), dim3(nb), dim3(256), 0, st, x, w, ws, R, K, N);
+        }
+        hipLaunchKernelGGL(dense_fwd_final_kernel, dim3((R * N + 63) / 64), dim3(256), 0, st, (const float*)ws, bias, y, R, N, nb, act, alpha);
+        return MMSEG_CHECK_LAUNCH();
+    }
     const int ks = dense_kslices(K);
     const int kper = (K + ks - 1) / ks;
     dim3 grid((N + 63) / 64, ks), block(256);
     if (R <= 8) hipLaunchKernelGGL(dense_fwd_partial_kernel<8>, grid, block, 0, st, x, w, ws, R, K, N, kper);
     else if (R <= 16) hipLaunchKernelGGL(dense_fwd_partial_kernel<16>, grid, block, 0, st, x, w, ws, R, K, N, kper);
     else hipLaunchKernelGGL(dense_fwd_partial_kernel<32>, grid, block, 0, st, x, w, ws, R, K, N, kper);
-    hipLaunchKernelGGL(dense_fwd_final_kernel, dim3((R * N + 255) / 256), dim3(256), 0, st, (const float*)ws, bias, y, R, N, ks, act, alpha);
+    hipLaunchKernelGGL(dense_fwd_final_kernel, dim3((R * N + 63) / 64), dim3(256), 0, st, (const float*)ws, bias, y, R, N, ks, act, alpha);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_dense_dgrad(const float* dy, const float* w, float* dx, int R, int K, int N, void* stream) {

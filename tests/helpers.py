@@ -108,3 +108,25 @@ def product_grads(model):
             if p.trainable:
                 out[prefix + p.name] = p.grad.detach().cpu().numpy().copy()
     return out
+
+
+def _mmsdnet_items(model):
+    return [('DM/', model.D_Mask), ('EA0/', model.Encoders_Anatomy[0]), ('EA1/', model.Encoders_Anatomy[1]),
+            ('FUS/', model.Anatomy_Fuser), ('EM/', model.Enc_Modality), ('SEG/', model.Segmentor), ('DEC/', model.Decoder)]
+
+
+def export_mmsdnet(model, dtype=torch.float64):
+    P = {}
+    for prefix, m in _mmsdnet_items(model):
+        for k, v in m.named_weights(prefix).items():
+            P[k] = torch.as_tensor(v, dtype=dtype)
+    return P
+
+
+def product_grads_mmsdnet(model):
+    out = {}
+    for prefix, m in _mmsdnet_items(model):
+        for p in m.params.values():
+            if p.trainable:
+                out[prefix + p.name] = p.grad.detach().cpu().numpy().copy()
+    return out
