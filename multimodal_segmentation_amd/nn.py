@@ -147,6 +147,7 @@ class Model(object):
             else:
                 p.data = self.state_arena[p.offset:p.offset + p.numel].view(p.shape)
         self.device = device
+        ops.bump_weight_version()      # parameter objects (cache keys of the weight re-layouts) may recycle ids
         return self
 
     # ---- keras.Model surface -------------------------------------------------------------------------------
@@ -285,7 +286,8 @@ def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, ups
     w = m.params[name + '/kernel']
     b = m.params.get(name + '/bias')
     return ops.conv2d(x, w.data, b.data if b is not None else None, stride, padding, act, alpha, x2, upsample,
-                      wgrad=w.g(), bgrad=b.g() if (b is not None and bias_grad) else None, anchor=anchor(x.device))
+                      wgrad=w.g(), bgrad=b.g() if (b is not None and bias_grad) else None, anchor=anchor(x.device),
+                      wkey=id(w))
 
 
 def dense(m, name, x, act=None, alpha=0.0):

@@ -59,9 +59,15 @@ def bump_weight_version():
     _weight_version[0] += 1
 
 
-def _wprep(w, KH, KW, Cin, Cout, mode):
-    """Cached [N][K] re-layout of a conv kernel for the fast path (mode 0: forward, 1: data gradient)."""
-    key = (w.data_ptr(), mode)
+def _wprep(w, KH, KW, Cin, Cout, mode, wkey=None):
+    """[N][K] re-layout of a conv kernel for the fast path (mode 0: forward, 1: data gradient).  Cached per weight
+    version when the caller identifies the weight (`wkey`, a parameter of an nn.Model whose arena is stable and whose
+    every update bumps the version); anonymous weights are re-laid out on every call."""
+    if wkey is None:
+        out = _ws('wprep%d' % mode, w.numel(), w.device)[:w.numel()]
+        N.call('mmseg_conv2d_wprep', w, out, KH, KW, Cin, Cout, mode)
+        return out
+    key = (wkey, w.data_ptr(), mode)
     ent = _wprep_cache.get(key)
     if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == w.numel():
         return ent[1]
@@ -71,10 +77,14 @@ def _wprep(w, KH, KW, Cin, Cout, mode):
     return out
 
 
-def _wprep_parity(w, KH, KW, Cin, Cout, stride, ph, pw, ntaps):
-    """Cached sub-kernel of one parity class of a strided convolution's data gradient (fast layout)."""
-    key = (w.data_ptr(), 'parity', stride, ph, pw)
+def _wprep_parity(w, KH, KW, Cin, Cout, stride, ph, pw, ntaps, wkey=None):
+    """Sub-kernel of one parity class of a strided convolution's data gradient (fast layout); cached like _wprep."""
     n = ntaps * Cin * Cout
+    if wkey is None:
+        out = _ws('wprep_parity', n, w.device)[:n]
+        N.call('mmseg_conv2d_wprep_parity', w, out, KH, KW, Cin, Cout, stride, ph, pw)
+        return out
+    key = (wkey, w.data_ptr(), 'parity', stride, ph, pw)
     ent = _wprep_cache.get(key)
     if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == n:
         return ent[1]
@@ -109,7 +119,7 @@ class _Conv2d(torch.autograd.Function):
     are accumulated into `wgrad` / `bgrad` (views of the owner's gradient arena) instead of being returned."""
 
     @staticmethod
-    def forward(ctx, x1, x2, anchor, w, bias, stride, padding, act, alpha, ups, wgrad, bgrad):
+    def forward(ctx, x1, x2, anchor, w, bias, stride, padding, act, alpha, ups, wgrad, bgrad, wkey):
         x1 = _c(x1)
         x2 = _c(x2) if x2 is not None else None
         B, H1, W1, C1 = x1.shape
@@ -121,11 +131,11 @@ class _Conv2d(torch.autograd.Function):
         assert Cin == C1 + C2, 'kernel expects %d input channels, got %d' % (Cin, C1 + C2)
         Ho, Wo, ph, pw = _conv_geometry(H, W, KH, KW, stride, padding)
         y = _new((B, Ho, Wo, Cout), x1)
-        wt = _wprep(w, KH, KW, Cin, Cout, 0) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
+        wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
         _conv_fwd_raw(x1, x2, w, wt, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,
                       ACT[act], alpha, 0)
         ctx.geom = (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), ACT[act], alpha)
-        ctx.wgrad, ctx.bgrad = wgrad, bgrad
+        ctx.wgrad, ctx.bgrad, ctx.wkey = wgrad, bgrad, wkey
         ctx.w = w     # plain (non-leaf) weight view: not tracked by autograd
         ctx.save_for_backward(x1, x2, y if ACT[act] else None)
         return y
@@ -164,12 +174,12 @@ class _Conv2d(torch.autograd.Function):
                 # strided convolution: one exact stride-1 launch per parity class of the input pixels
                 for qh in range(stride):
                     for qw in range(stride):
-                        wp = _wprep_parity(w, KH, KW, Cin, Cout, stride, qh, qw, taps[0][qh] * taps[1][qw])
+                        wp = _wprep_parity(w, KH, KW, Cin, Cout, stride, qh, qw, taps[0][qh] * taps[1][qw], ctx.wkey)
                         N.call('mmseg_conv2d_dgrad_parity', g, wp, d1, B, Ho, Wo, Cout, H, W, Cin, taps[0][qh], taps[1][qw],
                                stride, qh, qw)
             else:
                 if N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, tr):
-                    wf, wt = None, _wprep(w, KH, KW, Cin, Cout, 1)     # [Cin][flipped taps][Cout]
+                    wf, wt = None, _wprep(w, KH, KW, Cin, Cout, 1, ctx.wkey)     # [Cin][flipped taps][Cout]
                 else:
                     wf, wt = _ws('wflip', w.numel(), dy.device)[:w.numel()], None
                     N.call('mmseg_conv2d_wflip', w, wf, KH, KW, Cin, Cout)
@@ -182,18 +192,18 @@ class _Conv2d(torch.autograd.Function):
             else:
                 dx1 = d1
             dx2 = d2
-        return (dx1, dx2) + (None,) * 10
+        return (dx1, dx2) + (None,) * 11
 
 
 def conv2d(x, w, bias=None, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False,
-           wgrad=None, bgrad=None, anchor=None):
+           wgrad=None, bgrad=None, anchor=None, wkey=None):
     """keras Conv2D on NHWC (+ fused nearest x2 up-sampling of x, + fused channel concat with x2, + fused
     bias/activation epilogue).  `wgrad`/`bgrad`: gradient-arena views to accumulate into (None = frozen)."""
     if upsample and (x.shape[3] % 4 != 0):
         raise ValueError('fused up-sampling needs C % 4 == 0')
     if wgrad is None and bgrad is None:
         anchor = None
-    return _Conv2d.apply(x, x2, anchor, w, bias, stride, padding, act, alpha, bool(upsample), wgrad, bgrad)
+    return _Conv2d.apply(x, x2, anchor, w, bias, stride, padding, act, alpha, bool(upsample), wgrad, bgrad, wkey)
 
 
 # ------------------------------------------------------------------------------------------------------

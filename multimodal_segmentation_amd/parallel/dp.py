@@ -64,3 +64,5 @@ def broadcast_models(models, src=0):
     for m in models:
         dist.broadcast(m.arena, src=src)
         dist.broadcast(m.state_arena, src=src)
+    from .. import ops
+    ops.bump_weight_version()
