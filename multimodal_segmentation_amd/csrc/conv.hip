@@ -731,7 +731,7 @@ template <int BKT, int BNT, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradParams q) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BKT / WM / 32, TN = BNT / WN / 32;
-    constexpr int PT = 32;
+    constexpr int PT = 16;   // pixels per LDS stage: 16 keeps 4-5 blocks per CU resident (LDS 32 KB), which the 4-byte LDS operand reads need
     constexpr int AF4_PER_ROW = BKT / 4, A_RPP = NT / AF4_PER_ROW, A_F4 = (PT + A_RPP - 1) / A_RPP;
     constexpr int DF4_PER_ROW = BNT / 4, D_RPP = NT / DF4_PER_ROW, D_F4 = (PT + D_RPP - 1) / D_RPP;
     constexpr int A_SZ = PT * BKT, D_SZ = PT * BNT;
