@@ -51,6 +51,7 @@ class ConvTimer(object):
                     (B, Ho, Wo, Cout, H, W, Cin, TH, TW, stride, ph, pw) = args[3:15]
                     hs, ws = (H - ph + stride - 1) // stride, (W - pw + stride - 1) // stride
                     flops = 2.0 * B * hs * ws * Cin * TH * TW * Cout     # exact taps of this parity class
+                    nbytes = 4.0 * (B * Ho * Wo * Cout + TH * TW * Cin * Cout + B * hs * ws * Cin)
                     kind = 'conv_fwd_kernel'
                 elif name == 'mmseg_conv2d_fwd':
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[7:17]
@@ -59,25 +60,31 @@ class ConvTimer(object):
                     # forward convolution it differentiates, i.e. B*H*W (its INPUT pixels) x KH*KW x Cin x Cout
                     pix = B * H * W if transposed else B * Ho * Wo
                     flops = 2.0 * pix * Cout * KH * KW * (C1 + C2)
+                    ups = args[20]
+                    # algorithmic bytes: every input element, weight and output element once
+                    nbytes = 4.0 * (B * (H >> ups) * (W >> ups) * C1 + B * H * W * C2 + KH * KW * (C1 + C2) * Cout + B * Ho * Wo * Cout)
                     kind = 'conv_fwd_kernel'
                 else:
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[6:16]
                     flops = 2.0 * B * Ho * Wo * Cout * KH * KW * (C1 + C2)
+                    ups = args[19]
+                    nbytes = 4.0 * (B * (H >> ups) * (W >> ups) * C1 + B * H * W * C2 + KH * KW * (C1 + C2) * Cout + B * Ho * Wo * Cout)
                     kind = 'conv_wgrad_kernel'
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 rc = timer._orig(name, *args)
                 e.record()
-                timer.records.append((kind, flops, s, e))
+                timer.records.append((kind, flops, nbytes, s, e))
                 return rc
             return timer._orig(name, *args)
         _native.call = call
 
     def summary(self):
         out = {}
-        for kind, flops, s, e in self.records:
-            d = out.setdefault(kind, {'flops': 0.0, 'ms': 0.0, 'launches': 0})
+        for kind, flops, nbytes, s, e in self.records:
+            d = out.setdefault(kind, {'flops': 0.0, 'ms': 0.0, 'launches': 0, 'bytes': 0.0})
             d['flops'] += flops
+            d['bytes'] += nbytes
             d['ms'] += s.elapsed_time(e)
             d['launches'] += 1
         return out
@@ -200,18 +207,27 @@ def main():
         line['conv_roofline_frac_whole_step'] = TFLOP_PER_PAIR[key] * value / world / FP32_MFMA_PEAK_TFLOPS
     if rank == 0:
         summ = timer.summary() if not args.no_conv_timer else {}
+        traffic = {}
+        tpath = os.path.join(ROOT, 'profiles', 'r01_conv_traffic.json')
+        if os.path.exists(tpath) and (args.decoder, H, args.batch, args.l_mix) == ('film', 256, 8, 1.0):
+            traffic = json.load(open(tpath))     # HBM bytes per launch from rocprofv3 PMC passes of this same workload
         k = summ.get('conv_fwd_kernel')
         if k:
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
             line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (implicit-GEMM fp32 MFMA; forward + data-gradient launches)',
                                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
-                                'traffic': None, 'launches': k['launches'], 'avg_launch_ms': k['ms'] / k['launches'],
+                                'traffic': traffic.get('conv_fwd', {}).get('hbm_bytes_per_launch'),
+                                'algorithmic_bytes_per_launch': k['bytes'] / k['launches'],
+                                'flops_per_launch': k['flops'] / k['launches'],
+                                'launches': k['launches'], 'avg_launch_ms': k['ms'] / k['launches'],
                                 'gpu_ms_per_step': k['ms'] / args.steps}
         w = summ.get('conv_wgrad_kernel')
         if w:
             ach = w['flops'] / (w['ms'] * 1e-3) / 1e12
             line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv_wgrad_kernel (+ slab reduce)', 'achieved': ach,
                                       'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                                      'traffic': traffic.get('conv_wgrad', {}).get('hbm_bytes_per_launch'),
+                                      'algorithmic_bytes_per_launch': w['bytes'] / w['launches'],
                                       'launches': w['launches'], 'gpu_ms_per_step': w['ms'] / args.steps}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(H, args.decoder)

@@ -744,8 +744,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradPara
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 31, lh = lane >> 5;
-    const int k0 = blockIdx.x * BKT, n0 = blockIdx.y * BNT;
-    const int pbeg = blockIdx.z * q.chunk;
+    // 1-D grid, XCD-aware: the blocks that share a pixel chunk (all K tiles x N tiles of one split) are consecutive
+    // logical ids and therefore land on ONE XCD, so the chunk of x / dy is fetched into one L2 instead of eight
+    const int nkb = (p.K + BKT - 1) / BKT, nnb = (p.Cout + BNT - 1) / BNT;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int bz = lb / (nkb * nnb), brem = lb - bz * (nkb * nnb);
+    const int k0 = (brem % nkb) * BKT, n0 = (brem / nkb) * BNT;
+    const int pbeg = bz * q.chunk;
     const int pend = min(p.M, pbeg + q.chunk);
 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 4, 0x00020000);
@@ -851,7 +856,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradPara
         }
     }
 
-    float* out = q.ws + (size_t)blockIdx.z * p.K * p.Cout;
+    float* out = q.ws + (size_t)bz * p.K * p.Cout;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BNT / WN) + j * 32 + li;
@@ -868,7 +873,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradPara
 
 template <int BKT, int BNT, int WM, int WN>
 static int launch_wgrad_fast(const WgradParams& q, int S, hipStream_t st) {
-    dim3 grid((q.c.K + BKT - 1) / BKT, (q.c.Cout + BNT - 1) / BNT, S), block(WM * WN * 64);
+    dim3 grid(((q.c.K + BKT - 1) / BKT) * ((q.c.Cout + BNT - 1) / BNT) * S), block(WM * WN * 64);
     hipLaunchKernelGGL((conv_wgrad_fast_kernel<BKT, BNT, WM, WN>), grid, block, 0, st, q);
     return MMSEG_CHECK_LAUNCH();
 }
