@@ -565,6 +565,74 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
 }
 
 // =====================================================================================
+// Direct weight gradient of the 3x3, 8 -> 8 layers (FiLM decoder): dW[tap][ci][co] = sum_pix x[pix + tap][ci] * dy[pix][co].
+// 576 outputs only, so the work is a long reduction over pixels: a block stages an (8+2) x (64+2) input patch and the
+// 8 x 64 gradient tile in LDS in CHANNEL-MAJOR rows (so a lane's 4 consecutive pixels are one 16-byte LDS read); lane
+// (ci, co) of every wave keeps the 9 taps of its (ci, co) pair in registers; blocks write 576-float slabs that the
+// deterministic slab reduction sums.  VALU/LDS-bound, ~10x faster than pushing a 72 x 8 GEMM through 32x32 MFMA tiles.
+// =====================================================================================
+#define WG8_ROWS 8
+#define WG8_COLS 64
+#define WG8_LD 68
+__global__ __launch_bounds__(256) void conv_wgrad_c8_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ ws, int B, int H, int W, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float xs[(WG8_ROWS + 2) * 8 * WG8_LD];
+    __shared__ __attribute__((aligned(16))) float dys[WG8_ROWS * 8 * WG8_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ci = lane >> 3, co = lane & 7;
+    const int tpr = W / WG8_COLS, tpi = (H / WG8_ROWS) * tpr;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tpi, tr = tile - b * tpi;
+        const int r0 = (tr / tpr) * WG8_ROWS, c0 = (tr % tpr) * WG8_COLS;
+        __syncthreads();                                   // previous tile fully consumed
+        // stage the input patch (zero padded) and the gradient tile, channel-major rows
+        for (int i = tid; i < (WG8_ROWS + 2) * (WG8_COLS + 2) * 2; i += 256) {
+            const int half = i & 1, pc = (i >> 1) % (WG8_COLS + 2), pr = (i >> 1) / (WG8_COLS + 2);
+            const int hi = r0 + pr - 1, wi = c0 + pc - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + hi) * W + wi) * 8 + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xs[(pr * 8 + 4 * half + e) * WG8_LD + pc] = v[e];
+        }
+        for (int i = tid; i < WG8_ROWS * WG8_COLS * 2; i += 256) {
+            const int half = i & 1, pc = (i >> 1) % WG8_COLS, pr = (i >> 1) / WG8_COLS;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (((size_t)b * H + r0 + pr) * W + c0 + pc) * 8 + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dys[(pr * 8 + 4 * half + e) * WG8_LD + pc] = v[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < WG8_ROWS / 4; ++rr) {
+            const int row = wid * (WG8_ROWS / 4) + rr;
+#pragma unroll 4
+            for (int c4 = 0; c4 < WG8_COLS / 4; ++c4) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(&dys[(row * 8 + co) * WG8_LD + 4 * c4]);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const float* xr = &xs[((row + kh) * 8 + ci) * WG8_LD + 4 * c4];
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(xr);
+                    const float x4 = xr[4], x5 = xr[5];
+                    acc[kh * 3 + 0] += xa[0] * g[0] + xa[1] * g[1] + xa[2] * g[2] + xa[3] * g[3];
+                    acc[kh * 3 + 1] += xa[1] * g[0] + xa[2] * g[1] + xa[3] * g[2] + x4 * g[3];
+                    acc[kh * 3 + 2] += xa[2] * g[0] + xa[3] * g[1] + x4 * g[2] + x5 * g[3];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* red = xs;                                       // 4 waves x 576 partials
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[wid * 576 + t * 64 + lane] = acc[t];
+    __syncthreads();
+    for (int o = tid; o < 576; o += 256)
+        ws[(size_t)blockIdx.x * 576 + o] = red[o] + red[576 + o] + red[1152 + o] + red[1728 + o];
+}
+
+// =====================================================================================
 // wgrad: dW[k, n] = sum_m A[m, k] dy[m, n]
 // =====================================================================================
 struct WgradParams {
@@ -703,30 +771,45 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(WgradParams q)
     }
 }
 
-// dW[i] = sum_s ws[s][i]   (fixed order -> deterministic).  block = 64 float4 columns x 4 slab lanes
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n, int S) {
+// out[g][i] = sum_{s in group g} ws[s][i]   (fixed order -> deterministic).  block = 64 float4 columns x 4 slab lanes;
+// grid.y = number of slab groups (1 for the final pass).  Many slabs of a SMALL matrix (e.g. 1024 x 576 floats for the
+// 8 -> 8 layers) are reduced in two passes so that no thread walks more than ~8 slabs serially.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n, int S,
+                                                          int per_group) {
     __shared__ f32x4 sm[4][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long i4 = ((long)blockIdx.x * 64 + cl) * 4;
+    const int s0 = blockIdx.y * per_group, s1 = min(S, s0 + per_group);
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (i4 + 3 < n) {
 #pragma unroll 4
-        for (int s = sl; s < S; s += 4) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i4);
+        for (int s = s0 + sl; s < s1; s += 4) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i4);
     } else {
-        for (int s = sl; s < S; s += 4)
+        for (int s = s0 + sl; s < s1; s += 4)
             for (int e = 0; e < 4; ++e) if (i4 + e < n) a[e] += ws[(size_t)s * n + i4 + e];
     }
     sm[sl][cl] = a;
     __syncthreads();
     if (sl == 0) {
         const f32x4 t = sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl];
-        if (i4 + 3 < n) *reinterpret_cast<f32x4*>(out + i4) = t;
-        else for (int e = 0; e < 4; ++e) if (i4 + e < n) out[i4 + e] = t[e];
+        float* o = out + (size_t)blockIdx.y * n;
+        if (i4 + 3 < n) *reinterpret_cast<f32x4*>(o + i4) = t;
+        else for (int e = 0; e < 4; ++e) if (i4 + e < n) o[i4 + e] = t[e];
     }
 }
 
-// ---- wgrad fast path: buffer-load gather (each lane keeps ONE filter tap / channel quad for the whole launch, only its
-// pixel advances), hardware zero fill for padding taps / pixel tails, double-buffered LDS, one barrier per 32 pixels.
+// dW = sum of S slabs of n floats (ws is clobbered: the first-level partial sums are written over its first slabs' tail)
+static void launch_slab_reduce(const float* ws, float* tmp, float* dw, long n, int S, hipStream_t st) {
+    const unsigned nb = (unsigned)((n / 4 + 1 + 63) / 64);
+    if (S > 64 && tmp != nullptr) {
+        const int G = (S + 31) / 32;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb, G), dim3(256), 0, st, ws, tmp, n, S, 32);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb, 1), dim3(256), 0, st, (const float*)tmp, dw, n, G, G);
+    } else {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb, 1), dim3(256), 0, st, ws, dw, n, S, S);
+    }
+}
+
 template <int BKT, int BNT, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradParams q) {
     constexpr int NT = WM * WN * 64;
@@ -976,14 +1059,19 @@ int mmseg_conv2d_dgrad_parity(const float* dy, const float* wt, float* dx, int B
 }
 
 // number of floats of workspace mmseg_conv2d_wgrad needs for this geometry (0: writes dW directly)
-long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
-    const long M = (long)B * Ho * Wo, K = (long)KH * KW * Cin;
+// number of pixel splits (slabs) of the weight gradient: enough blocks to fill the chip, at least 512 pixels each
+static int wgrad_splits(long M, long K, int Cout) {
     const long tiles = ((K + 127) / 128) * ((Cout + 63) / 64);
     long S = (1024 + tiles - 1) / tiles;
     const long maxS = (M + 511) / 512;
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
-    return S == 1 ? 0 : S * K * Cout;
+    return (int)S;
+}
+long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+    const long M = (long)B * Ho * Wo, K = (long)KH * KW * Cin;
+    const long S = wgrad_splits(M, K, Cout);
+    return S == 1 ? 0 : (S + (S > 64 ? (S + 31) / 32 : 0)) * K * Cout;   // slabs (+ first-level partial sums)
 }
 
 int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
@@ -1002,11 +1090,20 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     const long need = mmseg_conv2d_wgrad_workspace(B, Ho, Wo, C1 + C2, Cout, KH, KW);
     if (need > ws_floats) return (int)hipErrorInvalidValue;
     const long KN = (long)p.K * Cout;
-    const int S = need == 0 ? 1 : (int)(need / KN);
+    const int S = wgrad_splits(p.M, p.K, Cout);
+    float* tmp = (S > 64) ? ws + (size_t)S * KN : nullptr;
     int chunk = (p.M + S - 1) / S;
     chunk = (chunk + 31) / 32 * 32;
     q.dy = dy; q.chunk = chunk; q.ws = S == 1 ? dw : ws;
     hipStream_t st = (hipStream_t)stream;
+    if (C1 == 8 && C2 == 0 && Cout == 8 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && !ups && Ho == H &&
+        Wo == W && H % WG8_ROWS == 0 && W % WG8_COLS == 0 && S > 1 && aligned16(x1) && aligned16(dy)) {
+        const int ntiles = B * (H / WG8_ROWS) * (W / WG8_COLS);
+        const int nblk = ntiles < S ? ntiles : S;
+        hipLaunchKernelGGL(conv_wgrad_c8_kernel, dim3(nblk), dim3(256), 0, st, x1, dy, ws, B, H, W, ntiles);
+        launch_slab_reduce(ws, tmp, dw, KN, nblk, st);
+        return MMSEG_CHECK_LAUNCH();
+    }
     const bool vec = (C1 % 4 == 0) && (C2 % 4 == 0) && aligned16(x1) && (C2 == 0 || aligned16(x2));
     int rc;
     const long lim = (1L << 31) - 64;
@@ -1018,8 +1115,7 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     else if (Cout > 32) rc = launch_wgrad<128, 64, 2, 2>(q, S, vec, st);
     else rc = launch_wgrad<128, 32, 4, 1>(q, S, vec, st);
     if (rc != 0 || S == 1) return rc;
-    const long n4 = (KN + 3) / 4;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, (const float*)ws, dw, KN, S);
+    launch_slab_reduce(ws, tmp, dw, KN, S, st);
     return MMSEG_CHECK_LAUNCH();
 }
 
