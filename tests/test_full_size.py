@@ -1,0 +1,137 @@
+"""Parity at BASELINE.json's full size (256x256, batch 8 per GPU): direct oracle comparisons where the oracle finishes in
+seconds, and size-independent properties of the domain elsewhere (linearity of the convolutions, fast path == generic
+path, BatchNorm moments, softmax/rounding invariants, identity warp, Adam closed form, whole-iteration sanity)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from multimodal_segmentation_amd import nn, ops as P
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+B, H = 8, 256
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def test_unet_d_l0_b_conv_against_oracle():
+    """The survey's minimum slice: conv3x3 on [8,256,256,64] -> 64 (UNet d_l0.b), forward + both gradients vs the oracle."""
+    x, w, b = rnd(B, H, H, 64, seed=1), rnd(3, 3, 64, 64, seed=2) * 0.06, rnd(64, seed=3) * 0.1
+    cot = rnd(B, H, H, 64, seed=4)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = O.conv2d(xr, wr, br)
+    yr.backward(cot)
+    xd = x.to(DEV).requires_grad_(True)
+    wd, bd = w.to(DEV), b.to(DEV)
+    wg, bg = torch.zeros_like(wd), torch.zeros_like(bd)
+    y = P.conv2d(xd, wd, bd, wgrad=wg, bgrad=bg, anchor=nn.anchor(xd.device))
+    y.backward(cot.to(DEV))
+    assert _rel(y.detach().cpu(), yr.detach()) < 1e-4        # oracle here is fp32 oneDNN: both carry ~1e-6 rounding
+    assert _rel(xd.grad.cpu(), xr.grad) < 1e-4
+    assert _rel(wg.cpu(), wr.grad) < 1e-3                    # 524288-term fp32 sums
+    assert _rel(bg.cpu(), br.grad) < 1e-3
+
+
+@pytest.mark.parametrize('cin,cout,hw', [(64, 64, 256), (128, 128, 128), (512, 256, 64), (1024, 1024, 16)])
+def test_conv_linearity_and_fast_vs_generic(cin, cout, hw):
+    """conv(a*x1 + x2) == a*conv(x1) + conv(x2) (bias-free), and the buffer-load fast path equals the generic kernel."""
+    from multimodal_segmentation_amd import _native as N
+    x1, x2 = rnd(B, hw, hw, cin, seed=5).to(DEV), rnd(B, hw, hw, cin, seed=6).to(DEV)
+    w = (rnd(3, 3, cin, cout, seed=7) * (2.0 / (9 * cin)) ** 0.5).to(DEV)
+    y1, y2 = P.conv2d(x1, w), P.conv2d(x2, w)
+    ysum = P.conv2d(P.axpby(x1, x2, 0.5, 1.0), w)
+    assert _rel(ysum, P.axpby(y1, y2, 0.5, 1.0)) < 2e-5
+    yg = torch.empty_like(y1)                                 # wt = None forces the generic kernel
+    N.call('mmseg_conv2d_fwd', x1, None, w, None, None, yg, None, B, hw, hw, cin, 0, hw, hw, cout, 3, 3, 1, 1, 1, 0, 0, 0, 0.0, 0)
+    assert _rel(y1, yg) < 2e-5
+
+
+def test_strided_dgrad_parity_classes_equal_fractionally_strided():
+    """Data gradient of the 4x4 stride-2 discriminator block at full size: 4 exact parity launches == dilated gather."""
+    from multimodal_segmentation_amd import _native as N
+    Bc, Hi, Ci, Co = 8, 127, 64, 128
+    Ho = (Hi - 4) // 2 + 1
+    g = rnd(Bc, Ho, Ho, Co, seed=8).to(DEV)
+    w = (rnd(4, 4, Ci, Co, seed=9) * 0.03).to(DEV)
+    x = rnd(Bc, Hi, Hi, Ci, seed=10).to(DEV).requires_grad_(True)
+    y = P.conv2d(x, w, None, stride=2, padding='valid')
+    y.backward(g)                                               # parity path (Cout % 32 == 0)
+    wf = torch.empty_like(w)
+    N.call('mmseg_conv2d_wflip', w, wf, 4, 4, Ci, Co)
+    dx = torch.empty(Bc, Hi, Hi, Ci, device=DEV)
+    N.call('mmseg_conv2d_fwd', g, None, wf, None, None, dx, None, Bc, Ho, Ho, Co, 0, Hi, Hi, Ci, 4, 4, 2, 3, 3, 0, 1, 0, 0.0, 0)
+    assert _rel(x.grad, dx) < 2e-5
+
+
+def test_batchnorm_moments_and_softmax_round_invariants():
+    x = (rnd(B, H, H, 64, seed=11) * 3 + 2).to(DEV)
+    g, b = (torch.rand(64) + 0.5).to(DEV), rnd(64, seed=12).to(DEV)
+    mm, mv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    y = P.batchnorm(x, g, b, mm, mv, True, relu=False)
+    yc = y.reshape(-1, 64).double()
+    assert (yc.mean(0).cpu() - b.cpu().double()).abs().max() < 1e-4          # mean = beta
+    assert (yc.var(0, unbiased=False).sqrt().cpu() / g.cpu().double() - 1).abs().max() < 2e-3   # std = gamma (eps 1e-3)
+    assert (mm.cpu() - 0.01 * x.reshape(-1, 64).mean(0).cpu()).abs().max() < 1e-5
+    logits = (rnd(B, H, H, 8, seed=13) * 4).to(DEV)
+    p, s = P.softmax_round(logits)
+    assert (p.sum(-1) - 1).abs().max() < 1e-5
+    assert bool(((s == 0) | (s == 1)).all()) and bool((s == torch.round(p)).all())
+    assert bool((s.sum(-1) <= 1).all())                                        # at most one channel can exceed 0.5
+
+
+def test_tps_identity_and_shift_at_full_size():
+    from multimodal_segmentation_amd.layers.stn_spline import ThinPlateSpline2D
+    tps = ThinPlateSpline2D((H, H), (5, 5), 8)
+    vol = (rnd(B, H, H, 8, seed=14) > 0).float().to(DEV)
+    out = tps([vol, torch.zeros(B, 25, 2, device=DEV)])
+    assert float((out - vol).abs().max()) < 1e-5
+    # a constant offset of every control point by k pixels (in normalised units) shifts the sampling grid by k pixels
+    theta = torch.zeros(B, 25, 2, device=DEV)
+    theta[..., 1] = 3.0 / (H - 1)                                              # +3 pixels along x
+    out = tps([vol, theta])
+    assert float((out[:, :, :-3] - vol[:, :, 3:]).abs().max()) < 1e-3
+    assert float(out[:, :, -3:].abs().max()) < 1e-3                            # taps beyond the image contribute zero
+
+
+def test_adam_closed_form_first_step():
+    n = 1 << 20
+    p0, g = rnd(n, seed=15).to(DEV), rnd(n, seed=16).to(DEV)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    lr_t = 1e-4 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    P.adam_step(p, g, m, v, lr_t)
+    # first step: m = 0.1 g, v = 0.001 g^2  ->  delta = -lr_t * 0.1 g / (sqrt(0.001) |g| + 1e-7)
+    ref = p0 - lr_t * 0.1 * g / (math.sqrt(0.001) * g.abs() + 1e-7)
+    assert float((p - ref).abs().max()) < 5e-7                 # a few fp32 ulps of |p| ~ 1; the update itself is ~3e-5
+
+
+def test_full_size_iteration_is_finite_and_learns_on_a_fixed_batch():
+    """Generator-only DAFNet iterations at 256x256, batch 8 on ONE fixed batch (discriminators frozen, so this is plain
+    minimisation): every loss finite and the weighted total decreases."""
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    conf = Hh.make_conf(dafnet_config_chaos, H, batch_size=B)
+    model = DAFNet(conf)
+    model.build()
+    d = Hh.make_step_data(B, H, H, seed=21)
+    tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [1.0] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [1.0] * 4 + [0.0] * 2 + [d['z1'], d['z2']]
+    rec = []
+    for _ in range(4):
+        h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']])
+        vals = {k: h.history[k][0] for k in h.history.keys()}
+        assert all(np.isfinite(v) for v in vals.values()), vals
+        rec.append(vals['loss'])
+    assert rec[-1] < rec[0], rec
+    m = model.Segmentor.predict(model.Encoders_Anatomy[0].predict(d['x1']))
+    assert m.shape == (B, H, H, 5) and abs(float(m.sum(-1).mean()) - 1) < 1e-4
