@@ -67,6 +67,69 @@ class SyntheticPairedData(object):
         sel = self.index == vol
         return self.images[mod_i][sel], self.masks[mod_i][sel]
 
+    # ---- container API of reference loaders/MultimodalPairedData.py used by the executors / tester ---------------
+    def get_volume_images_modi(self, mod_i, vol):
+        return self.images[mod_i][self.index == vol]
+
+    def get_volume_masks_modi(self, mod_i, vol):
+        return self.masks[mod_i][self.index == vol]
+
+    def set_images_modi(self, mod_i, images):
+        self.images[mod_i] = images
+
+    def set_masks_modi(self, mod_i, masks):
+        self.masks[mod_i] = masks
+
+    def filter_volumes(self, volumes):
+        """keep only the given volumes (MultimodalPairedData.py:46-62)"""
+        sel = np.isin(self.index, np.asarray(volumes))
+        self.images = [a[sel] for a in self.images]
+        self.masks = [a[sel] for a in self.masks]
+        self.index = self.index[sel]
+
+    def crop(self, shape):
+        """centre crop to `shape` (MultimodalPairedData.py:64-72); synthetic data is generated at the target size"""
+        H, W = self.images[0].shape[1:3]
+        if (H, W) == tuple(shape):
+            return
+        t, l = (H - shape[0]) // 2, (W - shape[1]) // 2
+        self.images = [a[:, t:t + shape[0], l:l + shape[1]] for a in self.images]
+        self.masks = [a[:, t:t + shape[0], l:l + shape[1]] for a in self.masks]
+
+    def sample_images(self, num, seed=-1):
+        if seed > -1:
+            np.random.seed(seed)
+        idx = np.random.choice(self.size(), size=num, replace=False)
+        return [a[idx] for a in self.images]
+
+    def randomise_pairs(self, length=3, seed=None):
+        """Re-pair every modality-2 slice with a modality-1 slice at most `length` slices away inside its volume
+        (MultimodalPairedData.py:143-167)."""
+        if seed is not None:
+            np.random.seed(seed)
+        new_images, new_masks = self.images[0].copy(), self.masks[0].copy()
+        for vol in self.volumes():
+            pos = np.where(self.index == vol)[0]
+            n = len(pos)
+            offsets = np.random.randint(-length, length, size=n) if length > 0 else np.zeros(n, int)
+            tgt = np.clip(np.arange(n) + offsets, 0, n - 1)
+            new_images[pos] = self.images[0][pos[tgt]]
+            new_masks[pos] = self.masks[0][pos[tgt]]
+        self.images[0], self.masks[0] = new_images, new_masks
+
+    def copy(self):
+        import copy
+        c = copy.copy(self)
+        c.images = [a.copy() for a in self.images]
+        c.masks = [a.copy() for a in self.masks]
+        c.index = self.index.copy()
+        return c
+
+    def merge(self, other):
+        self.images = [np.concatenate([a, b], 0) for a, b in zip(self.images, other.images)]
+        self.masks = [np.concatenate([a, b], 0) for a, b in zip(self.masks, other.masks)]
+        self.index = np.concatenate([self.index, other.index], 0)
+
 
 def splits():
     """14 train / 3 validation / 3 test volumes"""

@@ -16,7 +16,11 @@ import numpy as np
 import torch
 
 from .. import costs, nn
+from ..callbacks.swa import SWA
 from ..loaders import synthetic
+from ..model_components import anatomy_encoder, modality_encoder, anatomy_fuser, segmentor, decoder, balancer
+from ..model_tester import ModelTester
+from ..models.discriminator import Discriminator
 from ..utils import data_utils
 from ..utils.distributions import NormalDistribution
 from .base_executor import Executor, EarlyStopping
@@ -37,6 +41,39 @@ class DAFNetExecutor(Executor):
         self.ul_data = None
         self.device = model.D_Mask.device
         self.keep_losses_on_device = False
+        self.init_swa_models()
+
+    # ---- Stochastic Weight Averaging plumbing (dafnet_executor.py:41-68) -------------------------------------------
+    def init_swa_models(self):
+        c = self.conf
+        self.swa_D_Mask = SWA(40, Discriminator(c.d_mask_params).build, None)
+        has_image_d = hasattr(c, 'd_image_params') and getattr(self.model, 'D_Image1', None) is not None
+        self.swa_D_Image1 = SWA(40, Discriminator(c.d_image_params).build, None) if has_image_d else None
+        self.swa_D_Image2 = SWA(40, Discriminator(c.d_image_params).build, None) if has_image_d else None
+        self.swa_Enc_Anatomy1 = SWA(40, anatomy_encoder.build, c.anatomy_encoder)
+        self.swa_Enc_Anatomy2 = SWA(40, anatomy_encoder.build, c.anatomy_encoder)
+        self.swa_Enc_Modality = SWA(40, modality_encoder.build, c)
+        self.swa_Anatomy_Fuser = SWA(40, anatomy_fuser.build, c)
+        self.swa_Segmentor = SWA(40, segmentor.build, c)
+        self.swa_Decoder = SWA(40, decoder.build, c)
+        self.swa_Balancer = SWA(40, balancer.build, c) if getattr(self.model, 'Balancer', None) is not None else None
+        self.set_swa_model_weights()
+
+    def set_swa_model_weights(self):
+        m = self.model
+        pairs = [(self.swa_D_Mask, m.D_Mask), (self.swa_D_Image1, getattr(m, 'D_Image1', None)),
+                 (self.swa_D_Image2, getattr(m, 'D_Image2', None)), (self.swa_Enc_Anatomy1, m.Encoders_Anatomy[0]),
+                 (self.swa_Enc_Anatomy2, m.Encoders_Anatomy[1]), (self.swa_Enc_Modality, m.Enc_Modality),
+                 (self.swa_Anatomy_Fuser, m.Anatomy_Fuser), (self.swa_Segmentor, m.Segmentor), (self.swa_Decoder, m.Decoder),
+                 (self.swa_Balancer, getattr(m, 'Balancer', None))]
+        for swa, live in pairs:
+            if swa is not None:
+                swa.model = live
+
+    def get_swa_models(self):
+        return [s for s in (self.swa_D_Mask, self.swa_D_Image1, self.swa_D_Image2, self.swa_Enc_Anatomy1,
+                            self.swa_Enc_Anatomy2, self.swa_Enc_Modality, self.swa_Anatomy_Fuser, self.swa_Segmentor,
+                            self.swa_Decoder, self.swa_Balancer) if s is not None]
 
     # ---- data ----------------------------------------------------------------------------------------------------
     def init_train_data(self, device_resident=True, slices_per_volume=20, data_seed=1234):
@@ -83,7 +120,7 @@ class DAFNetExecutor(Executor):
     # ---- epoch loop (dafnet_executor.py:212-284) -------------------------------------------------------------------
     def train(self):
         log.info('Training Model')
-        self.init_train_data()
+        self.init_train_data(slices_per_volume=self.conf.get('slices_per_volume', 20))
         if not os.path.exists(self.conf.folder):
             os.makedirs(self.conf.folder)
         es = EarlyStopping('val_loss_mod2_fused', min_delta=0.01, patience=60)
@@ -97,6 +134,9 @@ class DAFNetExecutor(Executor):
             epoch_loss = {n: [] for n in loss_names}
             for self.batch in range(self.batches):
                 self.train_batch(epoch_loss)
+            self.set_swa_model_weights()
+            for swa_m in self.get_swa_models():
+                swa_m.on_epoch_end(self.epoch)
             self.validate(epoch_loss)
             for n in loss_names:
                 total_loss[n].append(np.mean([_f(v) for v in epoch_loss[n]]) if epoch_loss[n] else float('nan'))
@@ -105,42 +145,46 @@ class DAFNetExecutor(Executor):
                      ((self.epoch, self.conf.epochs) + tuple(total_loss[l][-1] for l in loss_names)))
             with open(csv_path, 'a') as f:
                 f.write('%d,' % self.epoch + ','.join('%.6f' % logs[l] for l in loss_names) + '\n')
-            self.model.save_models()
+            self.save_models()
             if self.stop_criterion(es, logs):
                 log.info('Finished training from early stopping criterion')
+                for swa_m in self.get_swa_models():
+                    swa_m.on_train_end()          # final model parameters = SWA averages (dafnet_executor.py:269-281)
+                self.save_models()
                 break
         return total_loss
 
+    def save_models(self, postfix=''):
+        """Checkpoints hold the SWA clones, one file per component under <folder>/models/ (dafnet_executor.py:286-301)"""
+        model_folder = self.conf.folder + '/models/'
+        if not os.path.exists(model_folder):
+            os.makedirs(model_folder)
+        names = [('D_Mask', self.swa_D_Mask), ('D_Image1', self.swa_D_Image1), ('D_Image2', self.swa_D_Image2),
+                 ('Enc_Anatomy1', self.swa_Enc_Anatomy1), ('Enc_Anatomy2', self.swa_Enc_Anatomy2),
+                 ('Enc_Modality', self.swa_Enc_Modality), ('Anatomy_Fuser', self.swa_Anatomy_Fuser),
+                 ('Segmentor', self.swa_Segmentor), ('Decoder', self.swa_Decoder), ('Balancer', self.swa_Balancer)]
+        for fname, swa in names:
+            if swa is not None:
+                swa.get_clone_model().save_weights(model_folder + fname + postfix)
+
     def test(self):
-        """Per-volume Dice on the synthetic test split for the 'simple' / 'def' / 'max' fusion modes
-        (reference model_tester.py:30-85)."""
-        sp = synthetic.splits()
-        data = synthetic.SyntheticPairedData(self.conf.input_shape, self.conf.num_masks, sp['test'], 20, 1234 + 202)
-        rows = []
-        for vol in data.volumes():
-            x1, _ = data.get_volume(0, vol)
-            x2, m2 = data.get_volume(1, vol)
-            for t in ('simple', 'def', 'max'):
-                pred = self.model.predict_mask(1, t, [x1, x2])
-                rows.append((vol, t, costs.dice(m2, pred, binarise=True)))
-        if not os.path.exists(self.conf.folder):
-            os.makedirs(self.conf.folder)
-        with open(self.conf.folder + '/results.csv', 'w') as f:
-            f.write('Vol,Type,Dice\n')
-            for r in rows:
-                f.write('%d,%s,%.6f\n' % r)
-        return rows
+        """Evaluate the model on the test split (reference base_executor.py:89-96 -> model_tester.py)"""
+        log.info('Evaluating model on test data')
+        tester = ModelTester(self.model, self.conf)
+        return tester.run()
 
     def validate(self, epoch_loss):
         """1 - Dice on the validation split for each modality / deformed / fused input (dafnet_executor.py:303-355)"""
         v = self.val_data
         x1, x2 = v.get_images_modi(0), v.get_images_modi(1)
         m1, m2 = v.get_masks_modi(0), v.get_masks_modi(1)
-        s1 = self.model.Encoders_Anatomy[0].predict(x1)
-        s2 = self.model.Encoders_Anatomy[1].predict(x2)
-        s1_def, s1_fused = self.model.Anatomy_Fuser.predict([s1, s2])
-        s2_def, s2_fused = self.model.Anatomy_Fuser.predict([s2, s1])
-        seg = self.model.Segmentor.predict
+        # validation runs on the SWA clones (dafnet_executor.py:319-335)
+        s1 = self.swa_Enc_Anatomy1.get_clone_model().predict(x1)
+        s2 = self.swa_Enc_Anatomy2.get_clone_model().predict(x2)
+        fuser = self.swa_Anatomy_Fuser.get_clone_model()
+        s1_def, s1_fused = fuser.predict([s1, s2])
+        s2_def, s2_fused = fuser.predict([s2, s1])
+        seg = self.swa_Segmentor.get_clone_model().predict
         l_mod1 = 1 - costs.dice(m1, seg(s1), binarise=True)
         l_mod2 = 1 - costs.dice(m2, seg(s2), binarise=True)
         l_mod2_mod1def = 1 - costs.dice(m2, seg(s1_def), binarise=True)

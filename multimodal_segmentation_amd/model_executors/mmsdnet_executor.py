@@ -33,10 +33,10 @@ class MMSDNetExecutor(DAFNetExecutor):
         v = self.val_data
         x1, x2 = v.get_images_modi(0), v.get_images_modi(1)
         m1, m2 = v.get_masks_modi(0), v.get_masks_modi(1)
-        s1 = self.model.Encoders_Anatomy[0].predict(x1)
-        s2 = self.model.Encoders_Anatomy[1].predict(x2)
-        s1_def, s_fused = self.model.Anatomy_Fuser.predict([s1, s2])
-        seg = self.model.Segmentor.predict
+        s1 = self.swa_Enc_Anatomy1.get_clone_model().predict(x1)
+        s2 = self.swa_Enc_Anatomy2.get_clone_model().predict(x2)
+        s1_def, s_fused = self.swa_Anatomy_Fuser.get_clone_model().predict([s1, s2])
+        seg = self.swa_Segmentor.get_clone_model().predict
         l_mod1 = 1 - costs.dice(m1, seg(s1), binarise=True)
         l_mod2 = 1 - costs.dice(m2, seg(s2), binarise=True)
         l_mod2_s1def = 1 - costs.dice(m2, seg(s1_def), binarise=True)

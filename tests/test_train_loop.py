@@ -1,0 +1,95 @@
+"""validation / test metrics with the reference's CSV layout, SWA, checkpoint layout, early stopping
+plumbing -- exercised end to end on a tiny synthetic split."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from multimodal_segmentation_amd import nn
+from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+from tests import helpers as Hh
+
+
+@pytest.fixture(params=[pytest.param('cpu', id='cpu-standin'), pytest.param('cuda', marks=pytest.mark.gpu, id='mi355x')])
+def device(request):
+    if request.param == 'cpu':
+        from tests import cpu_backend as cb
+        cb.install()
+        nn.set_default_device('cpu')
+        yield 'cpu'
+        cb.uninstall()
+    else:
+        nn.set_default_device('cuda:0')
+        yield 'cuda'
+
+
+def test_swa_running_average_and_clone(device):
+    """callbacks/swa.py:29-46: weights tracked up to swa_epoch, then averaged; the clone carries the averages."""
+    from multimodal_segmentation_amd.callbacks.swa import SWA
+    from multimodal_segmentation_amd.model_components import segmentor
+    conf = Hh.make_conf(dafnet_config_chaos, 64)
+    live = segmentor.build(conf)
+    swa = SWA(1, segmentor.build, conf)
+    swa.model = live
+    history = []
+    rng = np.random.RandomState(0)
+    for epoch in range(5):
+        ws = [w + rng.standard_normal(w.shape).astype(np.float32) * 0.01 for w in live.get_weights()]
+        live.set_weights(ws)
+        history.append(ws)
+        swa.on_epoch_end(epoch)
+    # epochs 0,1 copy; epochs 2..4 average: swa = mean(w1, w2, w3, w4)
+    expect = [np.mean([history[e][i] for e in range(1, 5)], axis=0) for i in range(len(history[0]))]
+    clone = swa.get_clone_model()
+    for a, b in zip(clone.get_weights(), expect):
+        assert np.abs(a - b).max() < 1e-6
+    x = rng.rand(1, 64, 64, 8).astype(np.float32)
+    swa.on_train_end()
+    assert np.abs(live.predict(x) - clone.predict(x)).max() < 1e-6
+
+
+def test_dice_metric_and_early_stopping():
+    from multimodal_segmentation_amd import costs
+    from multimodal_segmentation_amd.model_executors.base_executor import EarlyStopping
+    t = np.zeros((2, 4, 4, 2), np.float32); t[0, :2, :2, 0] = 1; t[1, 2:, 2:, 1] = 1
+    p = np.zeros((2, 4, 4, 3), np.float32); p[0, :2, :2, 0] = 0.9; p[1, 2:, :, 1] = 0.6
+    # sample 0: perfect (dice 1); sample 1: |int| = 4, |t| = 4, |p| = 8 -> 8/12
+    assert abs(costs.dice(t, p, binarise=True) - np.mean([1.0, 8.0 / 12.0])) < 1e-6
+    es = EarlyStopping('v', min_delta=0.01, patience=2)
+    for e, v in enumerate([1.0, 0.9, 0.895, 0.894, 0.5]):
+        es.on_epoch_end(e, {'v': v})
+        if es.stopped_epoch:
+            break
+    assert es.stopped_epoch == 3
+
+
+@pytest.mark.gpu
+def test_train_two_epochs_then_test_writes_reference_layout():
+    nn.set_default_device('cuda:0')
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
+    conf = Hh.make_conf(dafnet_config_chaos, 64, batch_size=4, epochs=2, slices_per_volume=2, test_dataset='chaos')
+    conf.folder = '/tmp/mmseg_test_train_loop'
+    shutil.rmtree(conf.folder, ignore_errors=True)
+    model = DAFNet(conf)
+    model.build()
+    ex = DAFNetExecutor(conf, model)
+    total = ex.train()
+    assert len(total['supervised_Mask']) == 2 and all(np.isfinite(v) for v in total['val_loss'])
+    rows = open(conf.folder + '/training.csv').read().strip().split('\n')
+    assert rows[0].split(',')[:3] == ['epoch', 'adv_M', 'adv_X1'] and len(rows) == 3
+    for f in ('D_Mask', 'D_Image1', 'D_Image2', 'Enc_Anatomy1', 'Enc_Anatomy2', 'Enc_Modality', 'Anatomy_Fuser', 'Segmentor',
+              'Decoder', 'Balancer'):
+        assert os.path.exists(conf.folder + '/models/' + f), f
+    res = ex.test()
+    assert len(res) == 12                                  # 2 modalities x {simple, def, max} x {expert, randomised pairs}
+    hdr = open(conf.folder + '/test_results_chaos_t2_max/results.csv').readline().strip()
+    assert hdr == 'Vol, Dice, Dice0, Dice1, Dice2, Dice3'
+    # a fresh model loads the checkpoint layout
+    model2 = DAFNet(conf)
+    model2.build()
+    a = model2.Segmentor.get_weights()
+    b = ex.swa_Segmentor.get_clone_model().get_weights()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
