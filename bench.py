@@ -90,14 +90,24 @@ class ConvTimer(object):
         return out
 
 
-def cpu_baseline(H, decoder):
+def host_cores():
+    """cores this process may actually use: the scheduler affinity (the GPU box exposes far more CPUs than its share), at
+    most 16 (the box's share for one GPU)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline_measure(H, decoder, B):
     """The oracle ("port") on the host cores: one full DAFNet iteration (generator fit + 2 mask-D fits + 2 image-D
-    fits incl. pools) at the benchmark's image size with batch 1."""
+    fits incl. pools) at the benchmark's image size and batch (about 10-30 s of CPU work).  Runs in a child process (see
+    cpu_baseline)."""
     from oracle import dafnet as OD, models as OM
     from tests import helpers as Hh
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
-    B = 1
     P = OM.build_dafnet_params(10, H, H, decoder)
     orc = OD.DAFNetOracle(P, dict(decoder_type=decoder))
     d = Hh.to_torch(Hh.make_step_data(B, H, H, seed=99), torch.float32)
@@ -105,8 +115,36 @@ def cpu_baseline(H, decoder):
     orc.train_batch(d, supervised=True)
     dt = time.time() - t0
     return {'value': B / dt, 'unit': 'paired slices/s', 'cores': cores, 'kind': 'port',
-            'sample': 'one full DAFNet-%s iteration at %dx%d with batch 1 (torch-CPU oracle, fp32, %d threads): %.1f s'
-                      % (decoder, H, H, cores, dt)}
+            'sample': 'one full DAFNet-%s iteration at %dx%d with batch %d (torch-CPU oracle, fp32, %d threads): %.1f s'
+                      % (decoder, H, H, B, cores, dt)}
+
+
+def cpu_baseline(H, decoder, B, limit_s=240):
+    """Time the oracle in a CPU-only child process with a hard limit, so that a slow or oversubscribed host can never
+    stall the benchmark line; on a timeout the baseline is reported as unmeasured."""
+    import subprocess
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', OMP_NUM_THREADS=str(host_cores()))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--size', str(H), '--decoder', decoder,
+           '--batch', str(B)]
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=limit_s,
+                             cwd=os.path.dirname(os.path.abspath(__file__)))
+        return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except Exception as exc:       # timeout, non-zero exit, unparsable output
+        return {'value': None, 'unit': 'paired slices/s', 'cores': host_cores(), 'kind': 'port',
+                'sample': 'unmeasured: oracle iteration at %dx%d batch %d did not finish within %d s (%s)'
+                          % (H, H, B, limit_s, type(exc).__name__)}
+
+
+_T0 = time.perf_counter()
+
+
+def _progress(msg):
+    """stage marker on stderr (stdout carries only the JSON line)"""
+    sys.stderr.write('[bench %7.1fs] %s\n' % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
 
 
 def main():
@@ -120,7 +158,11 @@ def main():
     ap.add_argument('--l_mix', type=float, default=1.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_measure(args.size, args.decoder, args.batch)))
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -153,12 +195,14 @@ def main():
     cfg['folder'] = '/tmp/mmseg_bench'
     conf = EasyDict(cfg)
 
+    _progress('building model')
     model = DAFNet(conf)
     model.build()
     dp.enable(world > 1)
     if world > 1:
         all_models = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
         dp.broadcast_models(all_models)
+    _progress('building executor + data')
     ex = DAFNetExecutor(conf, model)
     ex.keep_losses_on_device = True
     ex.init_train_data(device_resident=True, slices_per_volume=max(2, (2 * args.batch + 13) // 14))
@@ -172,10 +216,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    _progress('warmup')
     losses = {n: [] for n in ex.get_loss_names()}
     for _ in range(args.warmup):
         ex.train_batch(losses)
     sync()
+    _progress('timed region')
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -183,6 +229,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    _progress('timed region done: %.1f ms/step' % (1000.0 * dt / args.steps))
     if world > 1:
         tmax = torch.tensor([dt], device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -230,7 +277,8 @@ def main():
                                       'algorithmic_bytes_per_launch': w['bytes'] / w['launches'],
                                       'launches': w['launches'], 'gpu_ms_per_step': w['ms'] / args.steps}
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(H, args.decoder)
+            _progress('cpu baseline (oracle, bounded sample)')
+            line['cpu_baseline'] = cpu_baseline(H, args.decoder, args.batch)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

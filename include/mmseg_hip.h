@@ -136,6 +136,11 @@ int mmseg_tps_warp_fwd(const float* vol, const float* theta, const float* Mb, fl
 int mmseg_tps_warp_bwd(const float* vol, const float* loc, const float* Mb, const float* dout, float* dvol, float* dtheta, float* dloc,
                        float* ws, int B, int H, int W, int C, void* stream);
 
+/* ---- batch gather + affine (rotation) augmentation (csrc/augment.hip): keras ImageDataGenerator(rotation_range=20)
+ *      .flow of model_executors/base_executor.py:37-78,103-110 = scipy affine_transform(order=1, mode='nearest') ---- */
+int mmseg_affine_gather(const float* data, const int* rows, const float* mat, float* out, int B, int H, int W, int C, int order,
+                        void* stream);
+
 /* ---- losses (csrc/loss.hip): costs.py:43-85,129-136, keras mae/mse, costs.ypred ---------------------------- */
 int mmseg_segloss_workspace_floats(int B);
 int mmseg_segloss_stats_floats(int B);

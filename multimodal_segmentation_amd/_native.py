@@ -15,10 +15,10 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(CSRC_DIR, 'libmmseg_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'mmseg_hip.h')
-SOURCES = ('conv.hip', 'pointwise.hip', 'norm.hip', 'dense.hip', 'tps.hip', 'loss.hip', 'optim.hip')
+SOURCES = ('conv.hip', 'pointwise.hip', 'norm.hip', 'dense.hip', 'tps.hip', 'augment.hip', 'loss.hip', 'optim.hip')
 
 _CTYPES = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'void*': ctypes.c_void_p,
-           'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p}
+           'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p, 'const int*': ctypes.c_void_p}
 
 
 class NativeLibraryError(RuntimeError):
@@ -86,14 +86,15 @@ def _stream_handle(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _ptr(t, device):
+def _ptr(t, device, ctype='float*'):
     if t is None:
         return None
     if not isinstance(t, torch.Tensor):
         raise TypeError('expected a tensor or None, got %r' % type(t))
-    if t.dtype != torch.float32 or not t.is_contiguous() or t.device != device:
-        raise ValueError('kernel operands must be contiguous fp32 tensors on %s (got %s %s contiguous=%s)'
-                         % (device, t.dtype, t.device, t.is_contiguous()))
+    want = torch.int32 if 'int' in ctype else torch.float32
+    if t.dtype != want or not t.is_contiguous() or t.device != device:
+        raise ValueError('kernel operand (%s) must be a contiguous %s tensor on %s (got %s %s contiguous=%s)'
+                         % (ctype, want, device, t.dtype, t.device, t.is_contiguous()))
     return t.data_ptr()
 
 
@@ -112,8 +113,9 @@ def call(name, *args):
         if device is None or device.type != 'cuda':
             raise NativeLibraryError('%s needs device tensors (got %s); the HIP path has no CPU fallback' % (name, device))
     conv = []
-    for a in args:
-        conv.append(_ptr(a, device) if (a is None or isinstance(a, torch.Tensor)) else a)
+    for i, a in enumerate(args):
+        is_ptr = a is None or isinstance(a, torch.Tensor)
+        conv.append(_ptr(a, device, types[i] if i < len(types) else 'float*') if is_ptr else a)
     if takes_stream:
         conv.append(_stream_handle(device))
     if len(conv) != len(types):

@@ -1,10 +1,7 @@
-"""DAFNet / SPADE decoder on CHAOS (reference configuration/dafnet_spade_config_chaos.py): the FiLM config with
-folder 'dafnet_spade_chaos' and decoder_type 'spade'."""
-from . import dafnet_config_chaos as _base
+"""DAFNet with the SPADE decoder on CHAOS (reference configuration/dafnet_spade_config_chaos.py)."""
+from . import _chaos
 
 
 def get():
-    p = _base.get()
-    p['folder'] = 'dafnet_spade_chaos'
-    p['decoder_type'] = 'spade'
-    return p
+    return _chaos.assemble('dafnet_spade_chaos', 'dafnet.DAFNet', 'dafnet_executor.DAFNetExecutor', d_mask_filters=64,
+                           d_image_filters=64, decoder_type='spade', randomise=False, automatedpairing=False)

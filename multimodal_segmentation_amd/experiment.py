@@ -1,8 +1,11 @@
-"""Entry point (reference experiment.py:17-129): `python experiment.py --config <module in configuration/> --split <int>
-[--l_mix f] [--test b] [--test_dataset chaos] [--automatedpairing b] [--randomise b]`.
+"""Command-line entry point with the reference's interface (experiment.py:100-111):
 
-Config assembly mirrors Experiment.get_config (experiment.py:31-72): split, randomise, n_pairs, automatedpairing,
-l_mix, folder suffixes (dots stripped), test_dataset; the git hash is recorded when a repository is available.
+    python experiment.py --config <module in configuration/> --split <int> [--l_mix f] [--test b]
+                         [--test_dataset chaos] [--automatedpairing b] [--randomise b]
+
+The run folder name and the config mutations follow Experiment.get_config (experiment.py:31-72):
+`<folder>[_randomise][_automatedpairing]_l<l_mix>_<modality>_split<split>` with dots stripped, n_pairs = 3 under automated
+pairing else 1, `<folder>/experiment_configuration.json` written before and after training (74-78, 93-97).
 """
 import argparse
 import importlib
@@ -11,108 +14,116 @@ import logging
 import os
 import subprocess
 
-import numpy
+import numpy as np
 
 from .utils.config import EasyDict
+
+_PKG = __package__
+
+
+def parse_arguments(argv=None):
+    ap = argparse.ArgumentParser(description='multimodal segmentation experiment')
+    ap.add_argument('--config', required=True, help='module name under configuration/')
+    ap.add_argument('--split', required=True, help='data split index')
+    ap.add_argument('--test', type=bool, help='only evaluate on the test volumes')
+    ap.add_argument('--test_dataset', choices=['chaos'], help='override the configured test dataset')
+    ap.add_argument('--l_mix', help='fraction of labelled volumes')
+    ap.add_argument('--automatedpairing', type=bool, help='learn the pairing weights (n_pairs = 3)')
+    ap.add_argument('--randomise', type=bool, help='randomise the multimodal pairs')
+    return ap.parse_args(argv)
+
+
+def _flag(config, args, name):
+    return bool(config.get(name, False)) or bool(getattr(args, name, None))
+
+
+def folder_name(base, randomise, automatedpairing, l_mix, modality, split):
+    parts = [base]
+    if randomise:
+        parts.append('randomise')
+    if automatedpairing:
+        parts.append('automatedpairing')
+    parts += ['l%s' % l_mix, str(modality), 'split%s' % split]
+    return '_'.join(parts).replace('.', '')
+
+
+def git_hash():
+    try:
+        return subprocess.check_output(['git', 'rev-parse', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return ''
+
+
+def _jsonable(o):
+    if isinstance(o, np.integer):
+        return int(o)
+    if isinstance(o, np.floating):
+        return float(o)
+    raise TypeError(type(o))
+
+
+def resolve(subpackage, dotted):
+    """'dafnet.DAFNet' under models/ or model_executors/ -> class (experiment.py:115-123)"""
+    module, cls = dotted.split('.')
+    return getattr(importlib.import_module('%s.%s.%s' % (_PKG, subpackage, module)), cls)
 
 
 class Experiment(object):
     def __init__(self):
         self.log = None
 
-    def init_logging(self, config):
-        if not os.path.exists(config.folder):
-            os.makedirs(config.folder)
-        logging.basicConfig(filename=config.folder + '/logfile.log', level=logging.DEBUG, format='%(asctime)s %(message)s')
-        logging.getLogger().addHandler(logging.StreamHandler())
-        self.log = logging.getLogger()
-        self.log.debug(config.items())
-        self.log.info('---- Setting up experiment at ' + config.folder + '----')
-
+    # ---- configuration --------------------------------------------------------------------------------------------
     def get_config(self, split, args):
-        config_script = args.config
-        config_dict = importlib.import_module(__package__ + '.configuration.' + config_script).get()
-        config = EasyDict(config_dict)
-        config.split = split
+        conf = EasyDict(importlib.import_module('%s.configuration.%s' % (_PKG, args.config)).get())
+        conf.split = split
+        conf.randomise = _flag(conf, args, 'randomise')
+        conf.automatedpairing = _flag(conf, args, 'automatedpairing')
+        conf.n_pairs = 3 if conf.automatedpairing else 1
+        shown = conf.l_mix                       # the folder carries the string as typed on the command line
+        if getattr(args, 'l_mix', None) is not None:
+            conf.l_mix, shown = float(args.l_mix), args.l_mix
+        conf.folder = folder_name(conf.folder, conf.randomise, conf.automatedpairing, shown, conf.modality, split)
+        if getattr(args, 'test_dataset', None):
+            conf.test_dataset = args.test_dataset
+        conf.githash = git_hash()
+        self.save_config(conf)
+        return conf
 
-        if (hasattr(config, 'randomise') and config.randomise) or (hasattr(args, 'randomise') and args.randomise):
-            config.randomise = True
-            config.folder += '_randomise'
+    def save_config(self, conf):
+        os.makedirs(conf.folder, exist_ok=True)
+        with open(os.path.join(conf.folder, 'experiment_configuration.json'), 'w') as f:
+            json.dump(dict(conf.items()), f, default=_jsonable)
 
-        config.n_pairs = 1
-        if (hasattr(config, 'automatedpairing') and config.automatedpairing) or \
-                (hasattr(args, 'automatedpairing') and args.automatedpairing):
-            config.automatedpairing = True
-            config.folder += '_automatedpairing'
-            config.n_pairs = 3
+    def init_logging(self, conf):
+        os.makedirs(conf.folder, exist_ok=True)
+        logging.basicConfig(filename=os.path.join(conf.folder, 'logfile.log'), level=logging.DEBUG,
+                            format='%(asctime)s %(message)s')
+        root = logging.getLogger()
+        root.addHandler(logging.StreamHandler())
+        self.log = root
+        root.debug(conf.items())
+        root.info('---- Setting up experiment at ' + conf.folder + '----')
 
-        l_mix = config.l_mix
-        if getattr(args, 'l_mix', None) is not None:      # the reference raises on float(None) here (experiment.py:55-58)
-            config.l_mix = float(args.l_mix)
-            l_mix = args.l_mix
-        config.folder += '_l%s' % l_mix
+    # ---- run ----------------------------------------------------------------------------------------------------
+    def get_executor(self, conf, test=False):
+        model = resolve('models', conf.model)(conf)
+        model.build()
+        return resolve('model_executors', conf.executor)(conf, model)
 
-        config.folder += '_' + str(config.modality)
-        config.folder += '_split%s' % split
-        config.folder = config.folder.replace('.', '')
-
-        if args.test_dataset:
-            print('Overriding default test dataset')
-            config.test_dataset = args.test_dataset
-
-        try:
-            config.githash = subprocess.check_output(['git', 'rev-parse', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
-        except Exception:
-            config.githash = ''
-        self.save_config(config)
-        return config
-
-    def save_config(self, config):
-        if not os.path.exists(config.folder):
-            os.makedirs(config.folder)
-        with open(config.folder + '/experiment_configuration.json', 'w') as outfile:
-            json.dump(dict(config.items()), outfile)
+    def run_experiment(self, conf, test):
+        executor = self.get_executor(conf, test)
+        if not test:
+            executor.train()
+            self.save_config(conf)               # training adds keys (e.g. unlabelled counts)
+        executor.test()
 
     def run(self, argv=None):
-        args = Experiment.read_console_parameters(argv)
-        configuration = self.get_config(int(args.split), args)
-        self.init_logging(configuration)
-        self.run_experiment(configuration, args.test)
+        args = parse_arguments(argv)
+        conf = self.get_config(int(args.split), args)
+        self.init_logging(conf)
+        self.run_experiment(conf, args.test)
 
-    def run_experiment(self, configuration, test):
-        executor = self.get_executor(configuration, test)
-        if test:
-            executor.test()
-        else:
-            executor.train()
-
-            def default(o):
-                if isinstance(o, numpy.int64):
-                    return int(o)
-                raise TypeError
-            with open(configuration.folder + '/experiment_configuration.json', 'w') as outfile:
-                json.dump(dict(configuration.items()), outfile, default=default)
-            executor.test()
-
-    @staticmethod
-    def read_console_parameters(argv=None):
-        parser = argparse.ArgumentParser(description='')
-        parser.add_argument('--config', default='', help='The experiment configuration file', required=True)
-        parser.add_argument('--test', help='Evaluate the model on test data', type=bool)
-        parser.add_argument('--test_dataset', help='Override default test dataset', choices=['chaos'])
-        parser.add_argument('--split', help='Data split to run.', required=True)
-        parser.add_argument('--l_mix', help='Percentage of labelled data')
-        parser.add_argument('--automatedpairing', help='Use weighted cost for training', type=bool)
-        parser.add_argument('--randomise', help='Randomise multimodal pairs', type=bool)
-        return parser.parse_args(argv)
-
-    def get_executor(self, config, test):
-        module_name, model_name = config.model.split('.')
-        model = getattr(importlib.import_module(__package__ + '.models.' + module_name), model_name)(config)
-        model.build()
-        module_name, exec_name = config.executor.split('.')
-        executor = getattr(importlib.import_module(__package__ + '.model_executors.' + module_name), exec_name)(config, model)
-        return executor
+    read_console_parameters = staticmethod(parse_arguments)
 
 
 if __name__ == '__main__':

@@ -4,6 +4,8 @@ of reference loaders/MultimodalPairedData.py (get_images_modi / get_masks_modi /
 14/3/3 "volumes" x 20 slices (split sizes of reference loaders/chaos.py:34-37)."""
 import numpy as np
 
+from .MultimodalPairedData import MultimodalPairedData
+
 
 def smooth_field(rng, H, W, sigma):
     from scipy.ndimage import gaussian_filter
@@ -25,7 +27,7 @@ def ellipse_masks(rng, H, W, num_masks):
     return out
 
 
-class SyntheticPairedData(object):
+class SyntheticPairedData(MultimodalPairedData):
     """Two modalities of the same synthetic anatomy: modality 2 is a smooth intensity remap of modality 1 plus its
     own texture, organs are brighter/darker ellipses, so that segmentation is learnable."""
 
@@ -33,9 +35,9 @@ class SyntheticPairedData(object):
         H, W = input_shape[0], input_shape[1]
         rng = np.random.RandomState(seed)
         n = len(volumes) * slices_per_volume
-        self.images = [np.zeros((n, H, W, 1), np.float32) for _ in range(2)]
-        self.masks = [np.zeros((n, H, W, num_masks), np.float32) for _ in range(2)]
-        self.index = np.repeat(np.asarray(volumes), slices_per_volume)
+        images = np.zeros((n, H, W, 2), np.float32)
+        masks = np.zeros((n, H, W, 2 * num_masks), np.float32)
+        index = np.repeat(np.asarray(volumes), slices_per_volume)
         sigma = max(H / 32.0, 1.0)
         for i in range(n):
             m = ellipse_masks(rng, H, W, num_masks)
@@ -43,92 +45,14 @@ class SyntheticPairedData(object):
             for mod in range(2):
                 tex = smooth_field(rng, H, W, sigma)
                 img = 0.5 * tex + (organ if mod == 0 else -organ)
-                img = (img - img.min()) / (img.max() - img.min() + 1e-12) * 2 - 1
-                self.images[mod][i, ..., 0] = img
-                self.masks[mod][i] = m
-
-    def get_images_modi(self, mod_i):
-        return self.images[mod_i]
-
-    def get_masks_modi(self, mod_i):
-        return self.masks[mod_i]
-
-    def volumes(self):
-        return sorted(set(self.index.tolist()))
-
-    @property
-    def num_volumes(self):
-        return len(self.volumes())
-
-    def size(self):
-        return self.images[0].shape[0]
+                images[i, ..., mod] = (img - img.min()) / (img.max() - img.min() + 1e-12) * 2 - 1
+                masks[i, ..., mod * num_masks:(mod + 1) * num_masks] = m
+        super(SyntheticPairedData, self).__init__(images, masks, index)
+        self.image_dict = {k: np.ascontiguousarray(v) for k, v in self.image_dict.items()}
+        self.masks_dict = {k: np.ascontiguousarray(v) for k, v in self.masks_dict.items()}
 
     def get_volume(self, mod_i, vol):
-        sel = self.index == vol
-        return self.images[mod_i][sel], self.masks[mod_i][sel]
-
-    # ---- container API of reference loaders/MultimodalPairedData.py used by the executors / tester ---------------
-    def get_volume_images_modi(self, mod_i, vol):
-        return self.images[mod_i][self.index == vol]
-
-    def get_volume_masks_modi(self, mod_i, vol):
-        return self.masks[mod_i][self.index == vol]
-
-    def set_images_modi(self, mod_i, images):
-        self.images[mod_i] = images
-
-    def set_masks_modi(self, mod_i, masks):
-        self.masks[mod_i] = masks
-
-    def filter_volumes(self, volumes):
-        """keep only the given volumes (MultimodalPairedData.py:46-62)"""
-        sel = np.isin(self.index, np.asarray(volumes))
-        self.images = [a[sel] for a in self.images]
-        self.masks = [a[sel] for a in self.masks]
-        self.index = self.index[sel]
-
-    def crop(self, shape):
-        """centre crop to `shape` (MultimodalPairedData.py:64-72); synthetic data is generated at the target size"""
-        H, W = self.images[0].shape[1:3]
-        if (H, W) == tuple(shape):
-            return
-        t, l = (H - shape[0]) // 2, (W - shape[1]) // 2
-        self.images = [a[:, t:t + shape[0], l:l + shape[1]] for a in self.images]
-        self.masks = [a[:, t:t + shape[0], l:l + shape[1]] for a in self.masks]
-
-    def sample_images(self, num, seed=-1):
-        if seed > -1:
-            np.random.seed(seed)
-        idx = np.random.choice(self.size(), size=num, replace=False)
-        return [a[idx] for a in self.images]
-
-    def randomise_pairs(self, length=3, seed=None):
-        """Re-pair every modality-2 slice with a modality-1 slice at most `length` slices away inside its volume
-        (MultimodalPairedData.py:143-167)."""
-        if seed is not None:
-            np.random.seed(seed)
-        new_images, new_masks = self.images[0].copy(), self.masks[0].copy()
-        for vol in self.volumes():
-            pos = np.where(self.index == vol)[0]
-            n = len(pos)
-            offsets = np.random.randint(-length, length, size=n) if length > 0 else np.zeros(n, int)
-            tgt = np.clip(np.arange(n) + offsets, 0, n - 1)
-            new_images[pos] = self.images[0][pos[tgt]]
-            new_masks[pos] = self.masks[0][pos[tgt]]
-        self.images[0], self.masks[0] = new_images, new_masks
-
-    def copy(self):
-        import copy
-        c = copy.copy(self)
-        c.images = [a.copy() for a in self.images]
-        c.masks = [a.copy() for a in self.masks]
-        c.index = self.index.copy()
-        return c
-
-    def merge(self, other):
-        self.images = [np.concatenate([a, b], 0) for a, b in zip(self.images, other.images)]
-        self.masks = [np.concatenate([a, b], 0) for a, b in zip(self.masks, other.masks)]
-        self.index = np.concatenate([self.index, other.index], 0)
+        return self.get_volume_images_modi(mod_i, vol), self.get_volume_masks_modi(mod_i, vol)
 
 
 def splits():

@@ -1,6 +1,6 @@
 """Base class of the executors (reference model_executors/base_executor.py): batch alignment, the background
-("residual") mask channel, data iterators.  Augmentation (keras ImageDataGenerator, rotation +-20 degrees,
-base_executor.py:37-78,103-110) is a "next" row: the iterators below shuffle and batch only."""
+("residual") mask channel, and the augmenting data generators (keras ImageDataGenerator with +-20 degree rotations,
+base_executor.py:37-78,103-110 -> utils/augment.RotationFlow: shuffle, gather and rotate on the device)."""
 import logging
 
 import numpy as np
@@ -28,6 +28,29 @@ class Executor(object):
         """reference base_executor.py:112-119"""
         mn = np.min([x.shape[0] for x in array_list])
         return [x[0:mn] + 0. for x in array_list]
+
+    def get_datagen_params(self):
+        """augmentation switches of base_executor.py:103-110: only rotation_range is non-trivial"""
+        return dict(horizontal_flip=False, vertical_flip=False, rotation_range=20., width_shift_range=0, height_shift_range=0,
+                    zoom_range=0)
+
+    def get_data_generator(self, train_images=None, train_labels=None):
+        """Iterator over (images..., labels...) batches, all shuffled and rotated identically (base_executor.py:37-78: one
+        keras flow per array with a shared seed, zipped).  A single array yields bare batches instead of 1-tuples."""
+        from ..utils.augment import RotationFlow
+        arrays = []
+        for group in (train_images, train_labels):
+            if group is not None:
+                arrays += list(group) if isinstance(group, (list, tuple)) else [group]
+        if not arrays:
+            raise Exception('No data to iterate.')
+        p = self.get_datagen_params()
+        unsupported = [k for k in ('horizontal_flip', 'vertical_flip', 'width_shift_range', 'height_shift_range', 'zoom_range')
+                       if p.get(k)]
+        if unsupported:
+            raise NotImplementedError('augmentations not on the device path: %s' % unsupported)
+        return RotationFlow(arrays, self.conf.batch_size, self.conf.seed, self.device, rotation_range=p['rotation_range'],
+                            order=self.conf.get('augment_interpolation_order', 1))
 
     @staticmethod
     def batch_iterator(arrays, batch_size, rng):

@@ -76,39 +76,68 @@ class DAFNetExecutor(Executor):
                             self.swa_Decoder, self.swa_Balancer) if s is not None]
 
     # ---- data ----------------------------------------------------------------------------------------------------
-    def init_train_data(self, device_resident=True, slices_per_volume=20, data_seed=1234):
-        """Synthetic CHAOS-like split: round(l_mix * 14) labelled volumes (dafnet_executor.py:88,139), the rest
-        unlabelled; data seed 1234 + rank."""
+    def load_training_volumes(self, slices_per_volume=20, data_seed=1234):
+        """All 14 synthetic training volumes (the reference reads CHAOS here: loader.load_all_modalities_concatenated,
+        dafnet_executor.py:86); data seed 1234 + rank so that data-parallel ranks hold different slices."""
         from ..parallel import dp
-        sp = synthetic.splits()
-        n_lab = int(round(float(self.conf.l_mix) * len(sp['training'])))
-        shp, nm = self.conf.input_shape, self.conf.num_masks
-        seed = data_seed + dp.rank()
-        lab_vols = sp['training'][:max(n_lab, 1)]
-        self.data = synthetic.SyntheticPairedData(shp, nm, lab_vols, slices_per_volume, seed)
-        ul_vols = sp['training'][n_lab:] if n_lab < len(sp['training']) else []
-        self.ul_data = synthetic.SyntheticPairedData(shp, nm, ul_vols, slices_per_volume, seed + 1) if ul_vols else None
-        self.val_data = synthetic.SyntheticPairedData(shp, nm, sp['validation'], slices_per_volume, data_seed + 101)
-        rng = np.random.RandomState(seed + 7)
-        bs = self.conf.batch_size
+        vols = synthetic.splits()['training']
+        return synthetic.SyntheticPairedData(self.conf.input_shape, self.conf.num_masks, vols, slices_per_volume,
+                                             data_seed + dp.rank())
 
-        def dev(a):
-            return nn.to_device(a, self.device) if device_resident else a
+    def _pairing(self, data, seed=None):
+        """randomised / automated pairing of the training pairs (dafnet_executor.py:89-93,130-134)"""
+        n_pairs = self.conf.get('n_pairs', 1)
+        if self.conf.get('randomise', False):
+            data.randomise_pairs(n_pairs - 1, seed=seed)
+        elif self.conf.get('automatedpairing', False):
+            data.expand_pairs(n_pairs - 1, 0, neighborhood=n_pairs)
+            data.expand_pairs(n_pairs - 1, 1, neighborhood=n_pairs)
 
-        def it(arrays):
-            return self.batch_iterator([_Indexable(dev(a)) for a in arrays], bs, rng)
+    def init_train_data(self, device_resident=True, slices_per_volume=20, data_seed=1234):
+        """Generators of dafnet_executor.py:70-171 on the synthetic split: round(l_mix * 14) labelled volumes drawn with
+        conf.seed, the complement unlabelled; every generator shuffles, batches and rotates on the device
+        (utils/augment.py).  `device_resident` is kept for callers of earlier revisions: batches are always produced on
+        the executor's device."""
+        conf = self.conf
+        self.data, self.ul_data, self.data_len = None, None, 0
+        if conf.l_mix > 0:                                   # _init_labelled_data_generator (78-99)
+            self.data = self.load_training_volumes(slices_per_volume, data_seed)
+            self.data.sample(int(np.round(conf.l_mix * self.data.num_volumes)), seed=conf.seed)
+            self._pairing(self.data, seed=conf.seed)
+            self.data_len = self.data.size()
+            d = self.data
+            self.gen_labelled = self.get_data_generator(train_images=[d.get_images_modi(i) for i in range(2)],
+                                                        train_labels=[d.get_masks_modi(i) for i in range(2)])
+        if conf.l_mix < 1:                                   # _init_unlabelled_data_generator / _load_unlabelled_data (101-146)
+            u = self.load_training_volumes(slices_per_volume, data_seed)
+            conf.num_ul_volumes = u.num_volumes
+            self._pairing(u)
+            if conf.l_mix > 0:
+                labelled = u.get_sample_volumes(int(np.round(conf.l_mix * u.num_volumes)), seed=conf.seed)
+                u.filter_volumes([v for v in u.volumes() if v not in labelled])
+            self.ul_data = u
+            conf.unlabelled_image_num = u.size()
+            if self.data is None or u.size() > self.data.size():
+                self.data_len = u.size()
+            self.gen_unlabelled = self.get_data_generator(train_images=[u.get_images_modi(i) for i in range(2)],
+                                                          train_labels=[u.get_masks_modi(0)])
+        self.discriminator_masks = self.get_data_generator(train_labels=[self._load_discriminator_masks()])
+        everything = self.load_training_volumes(slices_per_volume, data_seed)    # 'all' data of a modality (141-143,168-171)
+        self.discriminator_image = [self.get_data_generator(train_images=[everything.get_images_modi(m)]) for m in range(2)]
+        self.val_data = synthetic.SyntheticPairedData(conf.input_shape, conf.num_masks, synthetic.splits()['validation'],
+                                                      slices_per_volume, data_seed + 101)
+        self.batches = int(np.ceil(self.data_len / float(conf.batch_size)))
 
-        d = self.data
-        self.gen_labelled = it([d.get_images_modi(0), d.get_images_modi(1), d.get_masks_modi(0), d.get_masks_modi(1)])
+    def _load_discriminator_masks(self):
+        """real masks for D_Mask: both modalities of the labelled data + modality 1 of the unlabelled (dafnet_executor.py:148-165)"""
+        masks = []
+        if self.data is not None:
+            masks.append(np.concatenate([self.data.get_masks_modi(0), self.data.get_masks_modi(1)], axis=0))
         if self.ul_data is not None:
-            u = self.ul_data
-            self.gen_unlabelled = it([u.get_images_modi(0), u.get_images_modi(1), u.get_masks_modi(0)])
-        all_masks = np.concatenate([d.get_masks_modi(0), d.get_masks_modi(1)], 0)
-        self.discriminator_masks = it([all_masks])
-        imgs = [np.concatenate([d.get_images_modi(m)] + ([self.ul_data.get_images_modi(m)] if self.ul_data else []), 0)
-                for m in range(2)]
-        self.discriminator_image = [it([imgs[0]]), it([imgs[1]])]
-        self.batches = int(np.ceil(d.size() / float(bs)))
+            masks.append(self.ul_data.get_masks_modi(0))
+        masks = np.concatenate(masks, axis=0)
+        assert masks.shape[1:3] == tuple(self.conf.input_shape[:2]), masks.shape
+        return masks
 
     def get_loss_names(self):
         return ['adv_M', 'adv_X1', 'adv_X2', 'rec_X', 'dis_M', 'dis_X1', 'dis_X2',
@@ -343,8 +372,9 @@ def _dev(x, device):
 
 
 def _add_residual_device(m):
-    """background = 1 where no mask is set (masks are {0,1} floats) -- pure data preparation on the device"""
-    res = (m.sum(-1, keepdim=True) < 0.5).to(m.dtype)
+    """background = 1 except where some mask equals 1 exactly (base_executor.py:83-87; after the bilinear rotation the
+    masks carry fractional edge values, which therefore count as background) -- pure data preparation on the device"""
+    res = 1.0 - (m == 1).any(-1, keepdim=True).to(m.dtype)
     return torch.cat([m, res], -1).contiguous()
 
 

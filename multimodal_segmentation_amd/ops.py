@@ -709,6 +709,15 @@ def axpby(a, b, sa=1.0, sb=1.0, out=None):
     return out
 
 
+def affine_gather(data, rows, mat, order=1):
+    """out[b] = affine resample (order 0/1, edge-clamped) of data[rows[b]] with the 2x3 matrix mat[b] in (row, col)
+    coordinates -- batch assembly + augmentation in one launch (csrc/augment.hip).  No gradient (input pipeline)."""
+    B = mat.shape[0]
+    out = _new((B,) + tuple(data.shape[1:]), data)
+    N.call('mmseg_affine_gather', data, rows, _c(mat), out, B, data.shape[1], data.shape[2], data.shape[3], int(order))
+    return out
+
+
 class _SteReplace(torch.autograd.Function):
     """Parity harness only: replace a rounded anatomy by a given tensor (teacher forcing across the Rounding
     discontinuity) while passing the gradient straight through.  No arithmetic."""

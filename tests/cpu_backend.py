@@ -456,6 +456,24 @@ def spectral_grad(w, sgn, scale, n, dw):
     dw.copy_(torch.sign(w) * sgn * scale); return 0
 
 
+def affine_gather(data, rows, mat, out, B, H, W, C, order):
+    src = data if rows is None else data.index_select(0, rows.long())
+    r = torch.arange(H, dtype=torch.float32).view(1, H, 1)
+    c = torch.arange(W, dtype=torch.float32).view(1, 1, W)
+    m = mat.view(B, 6, 1, 1)
+    sr = (m[:, 0] * r + m[:, 1] * c + m[:, 2]).clamp(0, H - 1)
+    sc = (m[:, 3] * r + m[:, 4] * c + m[:, 5]).clamp(0, W - 1)
+    if order == 0:
+        sr, sc = torch.floor(sr + 0.5), torch.floor(sc + 0.5)
+    r0, c0 = sr.floor().long().clamp(max=H - 1), sc.floor().long().clamp(max=W - 1)
+    r1, c1 = (r0 + 1).clamp(max=H - 1), (c0 + 1).clamp(max=W - 1)
+    ar, ac = (sr - r0).unsqueeze(-1), (sc - c0).unsqueeze(-1)
+    bi = torch.arange(B).view(B, 1, 1)
+    g = lambda rr, cc: src[bi, rr, cc]
+    out.copy_((1 - ar) * ((1 - ac) * g(r0, c0) + ac * g(r0, c1)) + ar * ((1 - ac) * g(r1, c0) + ac * g(r1, c1)))
+    return 0
+
+
 _TABLE = {('mmseg_' + k): v for k, v in list(globals().items()) if callable(v) and not k.startswith('_')
           and k not in ('install', 'uninstall')}
 

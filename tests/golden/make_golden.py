@@ -31,5 +31,20 @@ out['pool'] = pool
 img = np.arange(2 * 10 * 12 * 1, dtype=np.float32).reshape(2, 10, 12, 1)
 out['crop_same_in'] = img
 out['crop_same_out'] = data_utils.crop_same([img], [img], size=(8, 8))[0][0]
+# more crop / pad / rescale / normalise cases for the data containers: odd differences (the 'equal'
+# crop removes ceil(diff/2) on BOTH sides and is then padded back by one), constant and edge padding, left/right modes
+rs = np.random.RandomState(5)
+a = rs.rand(3, 11, 9, 2).astype(np.float32)
+b = rs.rand(3, 11, 9, 1).astype(np.float32)
+out['cs2_img'], out['cs2_msk'] = a, b
+for tag, kw in (('odd_const', dict(size=(8, 6), pad_mode='constant')), ('pad_edge', dict(size=(14, 12), pad_mode='edge')),
+                ('pad_const', dict(size=(14, 12), pad_mode='constant')), ('left', dict(size=(8, 6), mode='left')),
+                ('right', dict(size=(8, 6), mode='right')), ('mixed', dict(size=(14, 6), pad_mode='constant'))):
+    im, mk = data_utils.crop_same([a], [b], **kw)
+    out['cs2_%s_img' % tag], out['cs2_%s_msk' % tag] = im[0], mk[0]
+out['rescale_in'] = (rs.rand(2, 5, 5, 1) * 7 - 3)
+out['rescale_out'] = data_utils.rescale(out['rescale_in'])
+out['rescale_const_out'] = data_utils.rescale(np.full((2, 3, 3, 1), 4.0))
+out['normalise_out'] = data_utils.normalise(out['rescale_in'])
 np.savez(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'reference_helpers.npz'), **out)
 print('wrote', sorted(out))
