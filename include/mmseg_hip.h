@@ -150,6 +150,26 @@ int mmseg_segloss_stats(const float* pred, const float* target, float* stats, fl
 int mmseg_segloss_finalize(const float* stats, float* loss, float* coef, int B, int C, float n_pix_global, float lambda_bce, void* stream);
 int mmseg_segloss_grad(const float* pred, const float* target, const float* coef, float* dpred, int B, long HW, int C, int nm,
                        float scale, int use_bce, void* stream);
+/* ---- in-graph per-sample loss terms of the automated-pairing trainers (csrc/pairloss.hip): model_components/balancer.py:33-38
+ *      (pair dice), costs.py:24-26 (mae_single_input), costs.py:43-49,88-108,138-143 (combined dice + swapped-argument
+ *      per-batch cross-entropy), keras Multiply/Add of models/dafnet.py:290-312 (row dot) ------------------------------ */
+int mmseg_pairloss_workspace_floats(int B);
+int mmseg_pair_dice_fwd(const float* a, const float* b, float* stats, float* out, int ldo, float* ws, int B, long per_sample,
+                        void* stream);
+int mmseg_pair_dice_bwd(const float* a, const float* b, const float* stats, const float* g, int ldg, float* da, float* db,
+                        int accumulate_a, int B, long per_sample, void* stream);
+int mmseg_row_mae_fwd(const float* x, const float* y, float* out, float* ws, int B, long per_sample, void* stream);
+int mmseg_row_mae_bwd(const float* x, const float* y, const float* g, float* dy, int B, long per_sample, void* stream);
+int mmseg_segpb_stats_floats(int B);
+int mmseg_segpb_class_offset(int B);
+int mmseg_segpb_stats(const float* pred, const float* target, float* stats, float* ws, int B, long HW, int C, int nm, void* stream);
+int mmseg_segpb_loss(const float* stats, float* loss, int B, long HW, int C, float lambda_bce, void* stream);
+int mmseg_segpb_classgrad(const float* stats, const float* g, float* A, int B, void* stream);
+int mmseg_segpb_grad(const float* target, const float* stats, const float* g, const float* A, float* dpred, int B, long HW, int C,
+                     int nm, float lambda_bce, void* stream);
+int mmseg_rowdot_fwd(const float* w, const float* l, float* out, int B, int J, void* stream);
+int mmseg_rowdot_bwd(const float* w, const float* l, const float* g, float* dw, float* dl, int B, int J, void* stream);
+
 int mmseg_diffloss_workspace_floats(void);
 /* mode 0: mean|p-t|, 1: mean (p-t)^2, 2: mean p ; t == NULL -> constant target tconst */
 int mmseg_diffloss(const float* p, const float* t, float tconst, long n, int mode, float* loss, float* ws, void* stream);

@@ -15,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(CSRC_DIR, 'libmmseg_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'mmseg_hip.h')
-SOURCES = ('conv.hip', 'pointwise.hip', 'norm.hip', 'dense.hip', 'tps.hip', 'augment.hip', 'loss.hip', 'optim.hip')
+SOURCES = ('conv.hip', 'pointwise.hip', 'norm.hip', 'dense.hip', 'tps.hip', 'augment.hip', 'loss.hip', 'pairloss.hip', 'optim.hip')
 
 _CTYPES = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'void*': ctypes.c_void_p,
            'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p, 'const int*': ctypes.c_void_p}

@@ -1,9 +1,10 @@
-"""Balancer: similarity weights between anatomies from their Dice overlap (reference model_components/balancer.py).
-Built by DAFNet.build_generators (dafnet.py:129) but only USED by the automated-pairing graphs, which are a "next"
-row; the model exists so that the checkpoint layout and the SWA list are complete."""
+"""Balancer: similarity weights between anatomies from their Dice overlap (reference model_components/balancer.py:11-38):
+Dice of x1 against x2, x3, x4 -> Dense(5, relu) -> Dense(n_pairs) 'beta' -> softmax.  Built by DAFNet.build_generators
+(dafnet.py:129); used by the automated-pairing graphs (dafnet.py:286-290,352-361) and by validation
+(dafnet_executor.py:356-367).  Four inputs are hard-wired in the reference, hence n_pairs = 3."""
 import logging
 
-from .. import nn
+from .. import nn, ops
 from ..utils.rng import global_rng
 
 log = logging.getLogger('pair_selector')
@@ -18,7 +19,9 @@ class Balancer(nn.Model):
         self.finalize(rng)
 
     def forward(self, x1, x2, x3, x4, training=False):
-        raise NotImplementedError('Balancer forward belongs to the automated-pairing graph (SURVEY 8f rank 4)')
+        overlap = ops.overlap_dice(x1, [x2, x3, x4])                  # [B, 3]
+        l = nn.dense(self, 'd0', overlap, act='relu')
+        return ops.softmax(nn.dense(self, 'beta', l))
 
 
 def build(conf, rng=None):

@@ -204,7 +204,10 @@ class DAFNetExecutor(Executor):
 
     def validate(self, epoch_loss):
         """1 - Dice on the validation split for each modality / deformed / fused input (dafnet_executor.py:303-355)"""
-        v = self.val_data
+        v = self.val_data.copy()
+        if self.conf.get('randomise', False):
+            v.randomise_pairs(length=self.conf.n_pairs - 1)
+        v.crop(self.conf.input_shape[:2])
         x1, x2 = v.get_images_modi(0), v.get_images_modi(1)
         m1, m2 = v.get_masks_modi(0), v.get_masks_modi(1)
         # validation runs on the SWA clones (dafnet_executor.py:319-335)
@@ -224,18 +227,27 @@ class DAFNetExecutor(Executor):
                        ('val_loss_mod1_mod2def', l_mod1_mod2def), ('val_loss_mod2_fused', l_mod2_fused),
                        ('val_loss_mod1_fused', l_mod1_fused)):
             epoch_loss[k].append(val)
-        epoch_loss['val_loss'].append(np.mean([l_mod1, l_mod2, l_mod2_mod1def, l_mod1_mod2def, l_mod2_fused, l_mod1_fused]))
+        epoch_loss['val_loss'].append(np.mean([l_mod1, l_mod2, l_mod2_mod1def, l_mod2_fused]))   # dafnet_executor.py:354
+        if self.conf.get('automatedpairing', False):
+            # mean Balancer weight of every candidate, LIVE encoders / Balancer (dafnet_executor.py:356-367)
+            v.expand_pairs(self.conf.n_pairs - 1, 0, neighborhood=self.conf.n_pairs)
+            images0 = v.get_images_modi(0)
+            s1_list = [self.model.Encoders_Anatomy[0].predict(np.ascontiguousarray(images0[..., i:i + 1]))
+                       for i in range(images0.shape[-1])]
+            s2 = self.model.Encoders_Anatomy[1].predict(x2)
+            weights = self.model.Balancer.predict([s2] + s1_list)
+            for j in range(weights.shape[-1]):
+                epoch_loss['val_weight_%d' % j].append(float(np.mean(weights[..., j])))
 
     # ---- one iteration (dafnet_executor.py:369-387) ----------------------------------------------------------------
     def train_batch(self, epoch_loss):
-        if self.conf.automatedpairing:
-            raise NotImplementedError('automated pairing (SURVEY 8f rank 4)')
+        auto = bool(self.conf.get('automatedpairing', False))
         if self.conf.l_mix > 0:
-            self.train_supervised_expert_pairing(epoch_loss)
+            (self.train_supervised_automated_pairing if auto else self.train_supervised_expert_pairing)(epoch_loss)
             self.train_batch_mask_discriminator(epoch_loss)
             self.train_batch_image_discriminator(epoch_loss)
         if self.conf.l_mix < 1:
-            self.train_unsupervised_expert_pairing(epoch_loss)
+            (self.train_unsupervised_automated_pairing if auto else self.train_unsupervised_expert_pairing)(epoch_loss)
             self.train_batch_mask_discriminator(epoch_loss)
             self.train_batch_image_discriminator(epoch_loss)
 
@@ -245,20 +257,50 @@ class DAFNetExecutor(Executor):
             return _add_residual_device(m)
         return self.add_residual(m).astype(np.float32)
 
-    def prepare_data_to_train(self, x1, x2, m1, m2):
-        """dafnet_executor.py:482-500 (n_pairs = 1)"""
-        nm = self.conf.num_masks
-        m1 = self._residual(m1[..., 0:nm])
-        m2 = self._residual(m2[..., 0:nm]) if m2 is not None else None
-        batch_size = x1.shape[0]
+    def prepare_data_to_train(self, x1_pairs, x2_pairs, m1_pairs, m2_pairs):
+        """dafnet_executor.py:482-500: split the candidate pairs stacked on the channel axis, add the background channel,
+        draw the z samples of the Z-regressor branch."""
+        nm, n_pairs = self.conf.num_masks, self.conf.get('n_pairs', 1)
+
+        def split_images(x):
+            if x.shape[-1] == 1:
+                return [x]
+            return [x[..., i:i + 1].contiguous() if isinstance(x, torch.Tensor) else x[..., i:i + 1] for i in range(n_pairs)]
+        x1_list, x2_list = split_images(x1_pairs), split_images(x2_pairs)
+        m1 = self._residual(m1_pairs[..., 0:nm])
+        m2 = self._residual(m2_pairs[..., 0:nm]) if m2_pairs is not None else None
+        batch_size = x1_list[0].shape[0]
         norm = NormalDistribution()
         z1 = norm.sample((batch_size, self.conf.num_z)).astype(np.float32)
         z2 = norm.sample((batch_size, self.conf.num_z)).astype(np.float32)
-        return m1, m2, x1, x2, z1, z2
+        return m1, m2, x1_list[0], x1_list, x2_list[0], x2_list, z1, z2
+
+    def train_supervised_automated_pairing(self, epoch_loss):
+        """dafnet_executor.py:436-458: the weighted cross-modal terms are computed inside the graph, their targets are
+        placeholders (zeros)"""
+        x1_pairs, x2_pairs, m1_pairs, m2_pairs = next(self.gen_labelled)
+        m1, m2, x1, x1_list, x2, x2_list, z1, z2 = self.prepare_data_to_train(x1_pairs, x2_pairs, m1_pairs, m2_pairs)
+        h = self.model.supervised_trainer.fit(x1_list + x2_list + [m1, m2, z1, z2],
+                                              [m1, m2, 0.0, 0.0] +       # supervised cost
+                                              [1.0 for _ in range(4)] +  # mask adversarial
+                                              [x1, x2, 0.0, 0.0] +       # reconstruction cost
+                                              [1.0 for _ in range(4)] +  # image adversarial
+                                              [0.0 for _ in range(2)] +  # KL divergence
+                                              [z1, z2])
+        self.store_training_losses(h, epoch_loss)
+
+    def train_unsupervised_automated_pairing(self, epoch_loss):
+        """dafnet_executor.py:460-480"""
+        x1_pairs, x2_pairs, m1_pairs = next(self.gen_unlabelled)
+        m1, _, x1, x1_list, x2, x2_list, z1, z2 = self.prepare_data_to_train(x1_pairs, x2_pairs, m1_pairs, None)
+        h = self.model.unsupervised_trainer.fit(x1_list + x2_list + [m1, z1, z2],
+                                                [m1, 0.0] + [1.0 for _ in range(4)] + [x1, x2, 0.0, 0.0] +
+                                                [1.0 for _ in range(4)] + [0.0 for _ in range(2)] + [z1, z2])
+        self.store_training_losses(h, epoch_loss)
 
     def train_supervised_expert_pairing(self, epoch_loss):
         x1, x2, m1, m2 = next(self.gen_labelled)
-        m1, m2, x1, x2, z1, z2 = self.prepare_data_to_train(x1, x2, m1, m2)
+        m1, m2, x1, _, x2, _, z1, z2 = self.prepare_data_to_train(x1, x2, m1, m2)
         h = self.model.supervised_trainer.fit([x1, x2, z1, z2],
                                               [m1, m2, m1, m2] +      # supervised cost
                                               [1.0 for _ in range(4)] +  # mask adversarial (ones)
@@ -270,7 +312,7 @@ class DAFNetExecutor(Executor):
 
     def train_unsupervised_expert_pairing(self, epoch_loss):
         x1, x2, m1 = next(self.gen_unlabelled)
-        m1, _, x1, x2, z1, z2 = self.prepare_data_to_train(x1, x2, m1, None)
+        m1, _, x1, _, x2, _, z1, z2 = self.prepare_data_to_train(x1, x2, m1, None)
         h = self.model.unsupervised_trainer.fit([x1, x2, z1, z2],
                                                 [m1, m1] + [1.0 for _ in range(4)] + [x1, x2, x1, x2] +
                                                 [1.0 for _ in range(4)] + [0.0 for _ in range(2)] + [z1, z2])

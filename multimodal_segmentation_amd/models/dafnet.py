@@ -102,7 +102,7 @@ class DAFNet(MMSDNet):
         if not self.conf.automatedpairing:
             self.build_trainers_expertpairs()
         else:
-            raise NotImplementedError('automated pairing graph (dafnet.py:224-334) is a "next" row (SURVEY 8f rank 4)')
+            self.build_trainers_automatedpairs()
 
     def build_z_regressor(self):
         self.Z_Regressor = self._z_regressor(2)       # dafnet.py:336-350
@@ -169,6 +169,105 @@ class DAFNet(MMSDNet):
                [OutputSpec(n, 'mse', c.w_adv_X) for n in ('D_Image1', 'D_Image2', 'D_Image1', 'D_Image2')] + \
                [OutputSpec('Enc_Modality', costs.ypred, c.w_kl) for _ in range(2)] + \
                [OutputSpec('ZReconstruct', 'mae', c.w_rec_Z) for _ in range(2)]
+
+    # ---- automated pairing (dafnet.py:224-334,352-361) ---------------------------------------------------------------------
+    def calculate_weights(self, inputs):
+        """Balancer weights [B, n_pairs] of the candidate anatomies inputs[1:] against inputs[0] (dafnet.py:352-361);
+        None for a single candidate."""
+        if len(inputs) - 1 == 1:
+            return None
+        return self.Balancer(*inputs)
+
+    def _automated_graph(self, supervised):
+        """get_params_automated_pairing (dafnet.py:248-334).  Inputs x1_lst + x2_lst + [m1, (m2,) z1_input, z2_input]; every
+        modality contributes n_pairs candidate slices, the first being the expert pair.  The cross-modal segmentation
+        and reconstruction terms are computed per sample INSIDE the graph for every candidate and mixed with the
+        Balancer weights (outputs 'SegmentorDef' / 'DecoderDef', loss = costs.ypred)."""
+        nm, n = self.conf.num_masks, self.conf.n_pairs
+        from ..parallel import dp
+
+        def graph(ins, training=True, eps=None, teacher_s=None):
+            x1_lst, x2_lst = list(ins[:n]), list(ins[n:2 * n])
+            rest = list(ins[2 * n:])
+            m1_input = rest.pop(0)
+            m2_input = rest.pop(0) if supervised else None
+            z1_input, z2_input = rest
+            x1, x2 = x1_lst[0], x2_lst[0]
+            eps = eps or [None, None]
+            hook = dp.class_sum_hook()
+            seg_loss = lambda t, m: ops.seg_loss_per_sample(t, m, nm, costs.lambda_bce, hook)
+            with _Frozen([self.D_Mask, self.D_Image1, self.D_Image2]):
+                # encode every candidate
+                s1_lst = [self.Encoders_Anatomy[0](x, training=training) for x in x1_lst]
+                s2_lst = [self.Encoders_Anatomy[1](x, training=training) for x in x2_lst]
+                if teacher_s is not None:           # parity harness: force the oracle's rounded anatomies
+                    s1_lst = [ops.ste_replace(s, t) for s, t in zip(s1_lst, teacher_s[0])]
+                    s2_lst = [ops.ste_replace(s, t) for s, t in zip(s2_lst, teacher_s[1])]
+                s1, s2 = s1_lst[0], s2_lst[0]
+                z1, kl1 = self.Enc_Modality(s1, x1, eps=eps[0])
+                z2, kl2 = self.Enc_Modality(s2, x2, eps=eps[1])
+                m1 = self.Segmentor(s1, training=training)
+                m2 = self.Segmentor(s2, training=training)
+                y1 = self.Decoder(s1, z1)
+                y2 = self.Decoder(s2, z2)
+                adv_m = lambda m: self.D_Mask(ops.slice_channels(m, 0, nm))
+                adv_m1, adv_m2 = adv_m(m1), adv_m(m2)
+                adv_y1 = self.D_Image1(y1)
+                adv_y2 = self.D_Image2(y2)
+                # deform every candidate onto the other modality's expert slice; similarity weights
+                s1_def_lst = [self.Anatomy_Fuser(s1_i, s2)[0] for s1_i in s1_lst]
+                w1_def = self.calculate_weights([s2] + s1_def_lst)
+                s2_def_lst = [self.Anatomy_Fuser(s2_i, s1)[0] for s2_i in s2_lst]
+                w2_def = self.calculate_weights([s1] + s2_def_lst)
+                # weighted cross-reconstruction
+                y2_s1_def_lst = [self.Decoder(s, z2) for s in s1_def_lst]
+                y1_s2_def_lst = [self.Decoder(s, z1) for s in s2_def_lst]
+                y2_s1_def = ops.row_dot(w1_def, [ops.row_mae(x2, y) for y in y2_s1_def_lst])
+                y1_s2_def = ops.row_dot(w2_def, [ops.row_mae(x1, y) for y in y1_s2_def_lst])
+                # weighted cross-segmentation
+                m1_s2_def_lst = [self.Segmentor(s, training=training) for s in s2_def_lst]
+                m1_s2_def = ops.row_dot(w2_def, [seg_loss(m1_input, m) for m in m1_s2_def_lst])
+                m2_s1_def_lst = [self.Segmentor(s, training=training) for s in s1_def_lst]
+                if supervised:
+                    m2_s1_def = ops.row_dot(w1_def, [seg_loss(m2_input, m) for m in m2_s1_def_lst])
+                # GANs on the expert pair's deformed results
+                adv_m2_s1_def, adv_m1_s2_def = adv_m(m2_s1_def_lst[0]), adv_m(m1_s2_def_lst[0])
+                adv_y2_s1_def = self.D_Image2(y2_s1_def_lst[0])
+                adv_y1_s2_def = self.D_Image1(y1_s2_def_lst[0])
+                z1_rec = self.Enc_Modality(s1, self.Decoder(s1, z1_input), mu_only=True)
+                z2_rec = self.Enc_Modality(s2, self.Decoder(s2, z2_input), mu_only=True)
+            all_outputs = [m1, m2, m1_s2_def, m2_s1_def] if supervised else [m1, m1_s2_def]
+            all_outputs += [adv_m1, adv_m2, adv_m1_s2_def, adv_m2_s1_def] + \
+                           [y1, y2, y1_s2_def, y2_s1_def] + \
+                           [adv_y1, adv_y2, adv_y1_s2_def, adv_y2_s1_def] + \
+                           [kl1, kl2, z1_rec, z2_rec]
+            self.last_factors = {'s1': s1, 's2': s2, 's1_lst': s1_lst, 's2_lst': s2_lst, 's1_def_lst': s1_def_lst,
+                                 's2_def_lst': s2_def_lst, 'w1_def': w1_def, 'w2_def': w2_def, 'z1': z1, 'z2': z2}
+            return all_outputs
+        return graph
+
+    def _automated_specs(self, supervised):
+        """loss table of build_trainers_automatedpairs (dafnet.py:229-235)"""
+        c = self.conf
+        seg = costs.make_combined_dice_bce(self.num_masks)
+        seg_specs = [OutputSpec('Segmentor', seg, c.w_sup_M)] * (2 if supervised else 1) + \
+                    [OutputSpec('SegmentorDef', costs.ypred, c.w_sup_M)] * (2 if supervised else 1)
+        return seg_specs + \
+            [OutputSpec('D_Mask', 'mse', c.w_adv_M) for _ in range(4)] + \
+            [OutputSpec('Decoder', 'mae', c.w_rec_X) for _ in range(2)] + \
+            [OutputSpec('DecoderDef', costs.ypred, c.w_rec_X) for _ in range(2)] + \
+            [OutputSpec(nme, 'mse', c.w_adv_X) for nme in ('D_Image1', 'D_Image2', 'D_Image1', 'D_Image2')] + \
+            [OutputSpec('Enc_Modality', costs.ypred, c.w_kl) for _ in range(2)] + \
+            [OutputSpec('ZReconstruct', 'mae', c.w_rec_Z) for _ in range(2)]
+
+    def build_trainers_automatedpairs(self):
+        assert self.conf.n_pairs == 3, 'the Balancer is wired for 4 inputs = 1 reference + 3 candidates (balancer.py:17-22)'
+        gens = self._generator_models() + [self.Balancer]
+        frozen = [self.D_Mask, self.D_Image1, self.D_Image2]
+        self.unsupervised_trainer = Trainer('unsupervised_trainer', self._automated_graph(False), self._automated_specs(False),
+                                            gens, nn.Adam(self.conf.lr), self.num_masks, regularised=frozen)
+        self.supervised_trainer = Trainer('supervised_trainer', self._automated_graph(True), self._automated_specs(True),
+                                          gens, nn.Adam(self.conf.lr), self.num_masks, regularised=frozen)
 
     def build_trainers_expertpairs(self):
         """Two compiled models over the SAME generator weights, each with its own Adam (dafnet.py:140-161)."""

@@ -652,6 +652,144 @@ def seg_loss(pred, target, num_masks, lambda_bce, scale, class_sum_hook=None, n_
     return loss, dpred
 
 
+# ------------------------------------------------------------------------------------------------------
+# in-graph per-sample loss terms of the automated-pairing trainers (csrc/pairloss.hip)
+# ------------------------------------------------------------------------------------------------------
+class _OverlapDice(torch.autograd.Function):
+    """balancer.dice of one reference anatomy against J others -> [B, J] (model_components/balancer.py:21-22,33-38)"""
+
+    @staticmethod
+    def forward(ctx, ref, *others):
+        ref = _c(ref)
+        others = [_c(o) for o in others]
+        B, J = ref.shape[0], len(others)
+        per = ref.numel() // B
+        out = _new((B, J), ref)
+        stats = _new((J, B, 3), ref)
+        ws = _ws('pairloss', N.call('mmseg_pairloss_workspace_floats', B), ref.device)
+        for j, o in enumerate(others):
+            N.call('mmseg_pair_dice_fwd', ref, o, stats[j], _col(out, j),
+                   J, ws, B, per)
+        ctx.save_for_backward(ref, stats, *others)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ref, stats = ctx.saved_tensors[:2]
+        others = ctx.saved_tensors[2:]
+        g = _c(g)
+        B, J = g.shape
+        per = ref.numel() // B
+        dref = _new(ref.shape, ref)
+        douts = []
+        for j, o in enumerate(others):
+            do = _new(o.shape, o) if ctx.needs_input_grad[1 + j] else None
+            N.call('mmseg_pair_dice_bwd', ref, o, stats[j], _col(g, j), J, dref, do, int(j > 0), B, per)
+            douts.append(do)
+        return (dref if ctx.needs_input_grad[0] else None,) + tuple(douts)
+
+
+def _col(t, j):
+    """view of t[:, j:] flattened so that element [b, j] sits at offset b * row_stride (used with an explicit ld)"""
+    flat = t.reshape(-1)
+    return flat[j:]
+
+
+def overlap_dice(ref, others):
+    return _OverlapDice.apply(ref, *others)
+
+
+class _RowMAE(torch.autograd.Function):
+    """costs.mae_single_input: mean |x - y| over all but the batch axis -> [B]; gradient to y only (x is data)"""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _c(x), _c(y)
+        B = y.shape[0]
+        per = y.numel() // B
+        out = _new((B,), y)
+        ws = _ws('pairloss', N.call('mmseg_pairloss_workspace_floats', B), y.device)
+        N.call('mmseg_row_mae_fwd', x, y, out, ws, B, per)
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        B = y.shape[0]
+        dy = _new(y.shape, y)
+        N.call('mmseg_row_mae_bwd', x, y, _c(g), dy, B, y.numel() // B)
+        return None, dy
+
+
+def row_mae(x, y):
+    return _RowMAE.apply(x, y)
+
+
+class _SegLossPerSample(torch.autograd.Function):
+    """costs.make_combined_dice_bce_perbatch(num_masks)(y_true, y_pred) -> [B] (costs.py:138-143), including the
+    swapped-argument cross-entropy (class weights from the prediction over the whole batch, log-softmax of the labels)."""
+
+    @staticmethod
+    def forward(ctx, target, pred, num_masks, lambda_bce, class_sum_hook):
+        target, pred = _c(target), _c(pred)
+        B, H, W, C = pred.shape
+        stats = _new((N.call('mmseg_segpb_stats_floats', B),), pred)
+        ws = _ws('pairloss', N.call('mmseg_pairloss_workspace_floats', B), pred.device)
+        N.call('mmseg_segpb_stats', pred, target, stats, ws, B, H * W, C, num_masks)
+        if class_sum_hook is not None:
+            class_sum_hook(stats[N.call('mmseg_segpb_class_offset', B):])
+        loss = _new((B,), pred)
+        N.call('mmseg_segpb_loss', stats, loss, B, H * W, C, float(lambda_bce))
+        ctx.save_for_backward(target, stats)
+        ctx.meta = (B, H * W, C, num_masks, float(lambda_bce), class_sum_hook)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        target, stats = ctx.saved_tensors
+        B, HW, C, nm, lam, hook = ctx.meta
+        g = _c(g)
+        A = _new((8,), g)
+        N.call('mmseg_segpb_classgrad', stats, g, A, B)
+        if hook is not None:
+            hook(A)
+        dpred = _new(target.shape, target)
+        N.call('mmseg_segpb_grad', target, stats, g, A, dpred, B, HW, C, nm, lam)
+        return None, dpred, None, None, None
+
+
+def seg_loss_per_sample(target, pred, num_masks, lambda_bce=0.01, class_sum_hook=None):
+    return _SegLossPerSample.apply(target, pred, num_masks, lambda_bce, class_sum_hook)
+
+
+class _RowDot(torch.autograd.Function):
+    """sum_j w[:, j] * l_j -> [B, 1]: keras Multiply + Add over the candidate pairs (models/dafnet.py:293-312)"""
+
+    @staticmethod
+    def forward(ctx, w, *ls):
+        w = _c(w)
+        B, J = w.shape
+        l = torch.stack([x.reshape(B) for x in ls], dim=1).contiguous()      # [B, J] gather of J*B scalars
+        out = _new((B, 1), w)
+        N.call('mmseg_rowdot_fwd', w, l, out, B, J)
+        ctx.save_for_backward(w, l)
+        ctx.shapes = [tuple(x.shape) for x in ls]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, l = ctx.saved_tensors
+        B, J = w.shape
+        dw, dl = _new(w.shape, w), _new(l.shape, l)
+        N.call('mmseg_rowdot_bwd', w, l, _c(g), dw, dl, B, J)
+        return (dw,) + tuple(dl[:, j].reshape(shp) for j, shp in enumerate(ctx.shapes))
+
+
+def row_dot(w, ls):
+    return _RowDot.apply(w, *ls)
+
+
 _DIFF_MODE = {'mae': 0, 'mse': 1, 'mean': 2}
 
 

@@ -80,6 +80,112 @@ class DAFNetOracle(object):
             out[k] = v
         return out
 
+    # ---- automated pairing: get_params_automated_pairing (dafnet.py:248-334) ---------------------------------------------
+    def generator_forward_auto(self, x1_lst, x2_lst, m1_t, m2_t, z1_in, z2_in, eps1, eps2, upd, supervised, teacher_s=None):
+        """x1_lst / x2_lst: n_pairs candidate slices per modality, the first being the expert pair.  The weighted
+        cross-modal terms (outputs 'SegmentorDef', 'DecoderDef') are per-sample tensors [B,1] computed in the graph.
+        `teacher_s` = ([s1 candidates], [s2 candidates]) replaces the rounded anatomies."""
+        P, nm = self.P, self.conf['num_masks']
+        out = OrderedDict()
+        s1_lst = [self.enc(x, 0, True, upd) for x in x1_lst]
+        s2_lst = [self.enc(x, 1, True, upd) for x in x2_lst]
+        out['s1_lst'], out['s2_lst'] = list(s1_lst), list(s2_lst)
+        if teacher_s is not None:
+            s1_lst = [s + (t - s).detach() for s, t in zip(s1_lst, teacher_s[0])]
+            s2_lst = [s + (t - s).detach() for s, t in zip(s2_lst, teacher_s[1])]
+        x1, x2, s1, s2 = x1_lst[0], x2_lst[0], s1_lst[0], s2_lst[0]
+        z1, kl1 = M.modality_encoder(s1, x1, eps1, P)
+        z2, kl2 = M.modality_encoder(s2, x2, eps2, P)
+        m1 = M.segmentor(s1, P, True, upd)
+        m2 = M.segmentor(s2, P, True, upd)
+        y1 = self.decoder(s1, z1, P)
+        y2 = self.decoder(s2, z2, P)
+        adv_m1 = M.discriminator(m1[..., :nm], P, 'DM/')
+        adv_m2 = M.discriminator(m2[..., :nm], P, 'DM/')
+        adv_y1 = M.discriminator(y1, P, 'DI1/')
+        adv_y2 = M.discriminator(y2, P, 'DI2/')
+        s1_def_lst = [M.anatomy_fuser(s, s2, P)[0] for s in s1_lst]
+        w1 = M.balancer(s2, *s1_def_lst, P)                       # calculate_weights([s2] + s1_def_lst), dafnet.py:352-361
+        s2_def_lst = [M.anatomy_fuser(s, s1, P)[0] for s in s2_lst]
+        w2 = M.balancer(s1, *s2_def_lst, P)
+        y2_s1_def_lst = [self.decoder(s, z2, P) for s in s1_def_lst]
+        y1_s2_def_lst = [self.decoder(s, z1, P) for s in s2_def_lst]
+        # keras Multiply([w [B,1], loss]) + Add (dafnet.py:293-297): per-sample weighted sums, [B,1]
+        y2_s1_def = sum(w1[:, j:j + 1] * O.mae_single_input(x2, y) for j, y in enumerate(y2_s1_def_lst))
+        y1_s2_def = sum(w2[:, j:j + 1] * O.mae_single_input(x1, y) for j, y in enumerate(y1_s2_def_lst))
+        seg = lambda t, m: O.combined_dice_bce_perbatch(t, m, nm).unsqueeze(1)   # [B] -> expand_dims by keras' _Merge
+        m1_s2_def_lst = [M.segmentor(s, P, True, upd) for s in s2_def_lst]
+        m1_s2_def = sum(w2[:, j:j + 1] * seg(m1_t, m) for j, m in enumerate(m1_s2_def_lst))
+        m2_s1_def_lst = [M.segmentor(s, P, True, upd) for s in s1_def_lst]
+        m2_s1_def = sum(w1[:, j:j + 1] * seg(m2_t, m) for j, m in enumerate(m2_s1_def_lst)) if supervised else None
+        adv_m2_s1_def = M.discriminator(m2_s1_def_lst[0][..., :nm], P, 'DM/')
+        adv_m1_s2_def = M.discriminator(m1_s2_def_lst[0][..., :nm], P, 'DM/')
+        adv_y2_s1_def = M.discriminator(y2_s1_def_lst[0], P, 'DI2/')
+        adv_y1_s2_def = M.discriminator(y1_s2_def_lst[0], P, 'DI1/')
+        z1_rec = M.modality_encoder_mu(s1, self.decoder(s1, z1_in, P), P)[0]
+        z2_rec = M.modality_encoder_mu(s2, self.decoder(s2, z2_in, P), P)[0]
+        for k, v in (('m1', m1), ('m2', m2), ('m1_s2_def', m1_s2_def), ('m2_s1_def', m2_s1_def),
+                     ('adv_m1', adv_m1), ('adv_m2', adv_m2), ('adv_m1_s2_def', adv_m1_s2_def),
+                     ('adv_m2_s1_def', adv_m2_s1_def),
+                     ('y1', y1), ('y2', y2), ('y1_s2_def', y1_s2_def), ('y2_s1_def', y2_s1_def),
+                     ('adv_y1', adv_y1), ('adv_y2', adv_y2), ('adv_y1_s2_def', adv_y1_s2_def),
+                     ('adv_y2_s1_def', adv_y2_s1_def),
+                     ('kl1', kl1), ('kl2', kl2), ('z1_rec', z1_rec), ('z2_rec', z2_rec), ('w1', w1), ('w2', w2)):
+            out[k] = v
+        out['s1_def_lst'], out['s2_def_lst'] = s1_def_lst, s2_def_lst
+        return out
+
+    def generator_losses_auto(self, out, x1, x2, m1_t, m2_t, z1_in, z2_in, supervised):
+        """Loss table of build_trainers_automatedpairs (dafnet.py:229-235) in output order."""
+        c = self.conf
+        nm = c['num_masks']
+        terms = []
+        seg = lambda t, p: O.combined_dice_bce(t, p, nm)
+        if supervised:
+            terms += [('Segmentor', c['w_sup_M'], seg(m1_t, out['m1'])), ('Segmentor', c['w_sup_M'], seg(m2_t, out['m2'])),
+                      ('SegmentorDef', c['w_sup_M'], out['m1_s2_def'].mean()),
+                      ('SegmentorDef', c['w_sup_M'], out['m2_s1_def'].mean())]
+        else:
+            terms += [('Segmentor', c['w_sup_M'], seg(m1_t, out['m1'])), ('SegmentorDef', c['w_sup_M'], out['m1_s2_def'].mean())]
+        for k in ('adv_m1', 'adv_m2', 'adv_m1_s2_def', 'adv_m2_s1_def'):
+            terms.append(('D_Mask', c['w_adv_M'], O.mse(torch.ones_like(out[k]), out[k])))
+        terms += [('Decoder', c['w_rec_X'], O.mae(x1, out['y1'])), ('Decoder', c['w_rec_X'], O.mae(x2, out['y2'])),
+                  ('DecoderDef', c['w_rec_X'], out['y1_s2_def'].mean()), ('DecoderDef', c['w_rec_X'], out['y2_s1_def'].mean())]
+        for n, k in (('D_Image1', 'adv_y1'), ('D_Image2', 'adv_y2'), ('D_Image1', 'adv_y1_s2_def'),
+                     ('D_Image2', 'adv_y2_s1_def')):
+            terms.append((n, c['w_adv_X'], O.mse(torch.ones_like(out[k]), out[k])))
+        for k in ('kl1', 'kl2'):
+            terms.append(('Enc_Modality', c['w_kl'], out[k].mean()))
+        for t, k in ((z1_in, 'z1_rec'), (z2_in, 'z2_rec')):
+            terms.append(('ZReconstruct', c['w_rec_Z'], O.mae(t, out[k])))
+        total = sum(w * v for _, w, v in terms)
+        return total, [(n, v) for n, _, v in terms]
+
+    def generator_step_auto(self, x1_lst, x2_lst, m1_t, m2_t, z1_in, z2_in, eps1, eps2, supervised=True, teacher_s=None):
+        """supervised_trainer.fit / unsupervised_trainer.fit of the automated-pairing trainers (Balancer trainable)"""
+        if 'sup_auto' not in self.adam:
+            self.adam['sup_auto'], self.adam['unsup_auto'] = O.KerasAdam(self.conf['lr']), O.KerasAdam(self.conf['lr'])
+        names = M.trainable_names(self.P, GEN_PREFIXES + ('BAL/',))
+        self._with_grad(names)
+        upd = []
+        out = self.generator_forward_auto(x1_lst, x2_lst, m1_t, m2_t, z1_in, z2_in, eps1, eps2, upd, supervised, teacher_s)
+        total, terms = self.generator_losses_auto(out, x1_lst[0], x2_lst[0], m1_t, m2_t, z1_in, z2_in, supervised)
+        with torch.no_grad():
+            reg = sum(M.discriminator_reg(self.P, p) for p in ('DM/', 'DI1/', 'DI2/'))
+        self._step('sup_auto' if supervised else 'unsup_auto', names, total)
+        self._no_grad(names)
+        O.apply_bn_updates(self.P, upd)
+        hist = OrderedDict()
+        hist['loss'] = float(total.detach() + reg)
+        for n, v in terms:
+            hist[n + '_loss'] = float(v.detach())
+        flat = {}
+        for k, v in out.items():
+            flat[k] = [t.detach() for t in v] if isinstance(v, list) else (v.detach() if v is not None else None)
+        self.last_outputs = flat
+        self.last_terms = [(n, float(v.detach())) for n, v in terms]
+        return hist
+
     def generator_losses(self, out, x1, x2, m1_t, m2_t, z1_in, z2_in, supervised):
         """Loss table of build_trainers_expertpairs (dafnet.py:145-149) with the targets of
         train_(un)supervised_expert_pairing (dafnet_executor.py:404-435).  Returns

@@ -356,3 +356,42 @@ def add_residual(data):
     for i in range(data.shape[-1]):
         residual[data[..., i:i + 1] == 1] = 0
     return np.concatenate([data, residual], axis=-1)
+
+
+# ----------------------------------------------------------------------------
+# in-graph per-sample losses of the automated-pairing trainers
+# ----------------------------------------------------------------------------
+def pair_dice(a, b):
+    """model_components/balancer.py:33-38 -> [B, 1]"""
+    inter = (a * b).sum(dim=(1, 2, 3))
+    union = a.sum(dim=(1, 2, 3)) + b.sum(dim=(1, 2, 3))
+    return ((2 * inter + 1e-12) / (union + 1e-12)).unsqueeze(1)
+
+
+def mae_single_input(y1, y2):
+    """costs.py:24-26: K.mean(|y1 - y2|, axis=(1, 2)) -> [B, C] ([B, 1] for images)"""
+    return (y1 - y2).abs().mean(dim=(1, 2))
+
+
+def dice_coef_perbatch(y_true, y_pred):
+    """costs.py:43-49 -> [B]"""
+    inter = (y_true * y_pred).sum(dim=(1, 2, 3))
+    union = y_true.sum(dim=(1, 2, 3)) + y_pred.sum(dim=(1, 2, 3))
+    return 1 - (2 * inter + 1e-12) / (union + 1e-12)
+
+
+def weighted_cross_entropy_perbatch(y_pred, y_true):
+    """costs.py:88-108, with the parameter names of its declaration.  NOTE the only caller (costs.py:142) passes
+    (y_true, y_pred), i.e. swapped: class weights then come from the prediction, softmax + log is applied to the labels."""
+    B, H, W, C = y_true.shape
+    n = y_true.sum(dim=(0, 1, 2))
+    weights = n.sum() / (n + 1e-12)
+    sm = torch.softmax(y_pred.reshape(B, H * W, C), dim=-1)
+    ce = -(y_true.reshape(B, H * W, C) * torch.log(sm + 1e-12) * weights).sum(dim=2)
+    return ce.mean(dim=1)
+
+
+def combined_dice_bce_perbatch(y_true, y_pred, num_classes):
+    """costs.py:138-143 -> [B]"""
+    return dice_coef_perbatch(y_true[..., :num_classes], y_pred[..., :num_classes]) + \
+        0.01 * weighted_cross_entropy_perbatch(y_true, y_pred)

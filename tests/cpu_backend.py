@@ -456,6 +456,109 @@ def spectral_grad(w, sgn, scale, n, dw):
     dw.copy_(torch.sign(w) * sgn * scale); return 0
 
 
+def pairloss_workspace_floats(B):
+    return 16
+
+
+def pair_dice_fwd(a, b, stats, out, ldo, ws, B, per):
+    a2, b2 = a.reshape(-1)[:B * per].reshape(B, per), b.reshape(-1)[:B * per].reshape(B, per)
+    I, A, Bs = (a2 * b2).sum(1), a2.sum(1), b2.sum(1)
+    stats.reshape(-1)[:3 * B].copy_(torch.stack([I, A, Bs], 1).reshape(-1))
+    d = (2 * I + 1e-12) / (A + Bs + 1e-12)
+    out[:(B - 1) * ldo + 1:ldo].copy_(d)
+    return 0
+
+
+def pair_dice_bwd(a, b, stats, g, ldg, da, db, acc, B, per):
+    a2, b2 = a.reshape(B, per), b.reshape(B, per)
+    st = stats.reshape(-1)[:3 * B].reshape(B, 3)
+    den, num = st[:, 1] + st[:, 2] + 1e-12, 2 * st[:, 0] + 1e-12
+    gs = g[:(B - 1) * ldg + 1:ldg]
+    k1, k0 = (gs * 2 / den)[:, None], (-gs * num / den ** 2)[:, None]
+    ga = k1 * b2 + k0
+    if acc:
+        da.reshape(B, per).add_(ga)
+    else:
+        da.reshape(B, per).copy_(ga)
+    if db is not None:
+        db.reshape(B, per).copy_(k1 * a2 + k0)
+    return 0
+
+
+def row_mae_fwd(x, y, out, ws, B, per):
+    out.copy_((x.reshape(B, per) - y.reshape(B, per)).abs().mean(1))
+    return 0
+
+
+def row_mae_bwd(x, y, g, dy, B, per):
+    dy.reshape(B, per).copy_(torch.sign(y.reshape(B, per) - x.reshape(B, per)) * (g.reshape(B, 1) / per))
+    return 0
+
+
+def segpb_stats_floats(B):
+    return B * 11 + 8
+
+
+def segpb_class_offset(B):
+    return B * 11
+
+
+def _label_nll(t):
+    return -torch.log(torch.softmax(t, -1) + 1e-12)
+
+
+def segpb_stats(pred, target, stats, ws, B, HW, C, nm):
+    p, t = pred.reshape(B, HW, C), target.reshape(B, HW, C)
+    st = torch.zeros(B, 11)
+    st[:, 0] = (t[..., :nm] * p[..., :nm]).sum((1, 2))
+    st[:, 1] = t[..., :nm].sum((1, 2))
+    st[:, 2] = p[..., :nm].sum((1, 2))
+    st[:, 3:3 + C] = (p * _label_nll(t)).sum(1)
+    n = torch.zeros(8)
+    n[:C] = p.sum((0, 1))
+    stats.copy_(torch.cat([st.reshape(-1), n]))
+    return 0
+
+
+def segpb_loss(stats, loss, B, HW, C, lam):
+    st, n = stats[:B * 11].reshape(B, 11), stats[B * 11:B * 11 + C]
+    w = n.sum() / (n + 1e-12)
+    loss.copy_(1 - (2 * st[:, 0] + 1e-12) / (st[:, 1] + st[:, 2] + 1e-12) + lam / HW * (st[:, 3:3 + C] * w).sum(1))
+    return 0
+
+
+def segpb_classgrad(stats, g, A, B):
+    st = stats[:B * 11].reshape(B, 11)
+    A.copy_((g.reshape(B, 1) * st[:, 3:]).sum(0))
+    return 0
+
+
+def segpb_grad(target, stats, g, A, dpred, B, HW, C, nm, lam):
+    t = target.reshape(B, HW, C)
+    st, n = stats[:B * 11].reshape(B, 11), stats[B * 11:B * 11 + C]
+    N_ = n.sum()
+    d = n + 1e-12
+    w = N_ / d
+    K = (A[:C] / d).sum() - A[:C] * N_ / d ** 2
+    gb = g.reshape(B, 1, 1)
+    out = lam / HW * (gb * _label_nll(t) * w + K)
+    den, num = (st[:, 1] + st[:, 2] + 1e-12).reshape(B, 1, 1), (2 * st[:, 0] + 1e-12).reshape(B, 1, 1)
+    out[..., :nm] += gb * (-2 * t[..., :nm] / den + num / den ** 2)
+    dpred.copy_(out.reshape(dpred.shape))
+    return 0
+
+
+def rowdot_fwd(w, l, out, B, J):
+    out.copy_((w * l).sum(1, keepdim=True))
+    return 0
+
+
+def rowdot_bwd(w, l, g, dw, dl, B, J):
+    dw.copy_(g.reshape(B, 1) * l)
+    dl.copy_(g.reshape(B, 1) * w)
+    return 0
+
+
 def affine_gather(data, rows, mat, out, B, H, W, C, order):
     src = data if rows is None else data.index_select(0, rows.long())
     r = torch.arange(H, dtype=torch.float32).view(1, H, 1)

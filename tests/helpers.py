@@ -90,6 +90,8 @@ def export_dafnet(model, dtype=torch.float64):
              ('EA0/', model.Encoders_Anatomy[0]), ('EA1/', model.Encoders_Anatomy[1]),
              ('EAS/', model.Encoders_Anatomy[0].shared[0]), ('FUS/', model.Anatomy_Fuser), ('EM/', model.Enc_Modality),
              ('SEG/', model.Segmentor), ('DEC/', model.Decoder)]
+    if getattr(model, 'Balancer', None) is not None:
+        items.append(('BAL/', model.Balancer))
     for prefix, m in items:
         for k, v in m.named_weights(prefix).items():
             P[k] = torch.as_tensor(v, dtype=dtype)
@@ -103,6 +105,8 @@ def product_grads(model):
              ('EA0/', model.Encoders_Anatomy[0]), ('EA1/', model.Encoders_Anatomy[1]),
              ('EAS/', model.Encoders_Anatomy[0].shared[0]), ('FUS/', model.Anatomy_Fuser), ('EM/', model.Enc_Modality),
              ('SEG/', model.Segmentor), ('DEC/', model.Decoder)]
+    if getattr(model, 'Balancer', None) is not None:
+        items.append(('BAL/', model.Balancer))
     for prefix, m in items:
         for p in m.params.values():
             if p.trainable:

@@ -315,3 +315,42 @@ def test_adam(device):
         lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
         P.adam_step(pp, gt.to(device), m, v, lr_t)
     _close(pp, Pd['p'], 'adam', 1e-6)
+
+
+# ---- in-graph per-sample losses of the automated-pairing trainers ----------------------------------------------------
+def _anat(B, H, W, C, seed):
+    """one-hot-ish {0,1} anatomies like the rounded encoder output"""
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randint(0, C + 1, (B, H, W), generator=g)
+    return torch.nn.functional.one_hot(idx, C + 1)[..., :C].float()
+
+
+def test_overlap_dice(device):
+    B, H, W, C = 3, 16, 12, 8
+    ref = _anat(B, H, W, C, 1) * 0.9 + 0.05
+    others = [_anat(B, H, W, C, s) * 0.8 + 0.1 for s in (2, 3, 4)]
+    check(lambda r, a, b, c: P.overlap_dice(r, [a, b, c]),
+          lambda r, a, b, c: torch.cat([O.pair_dice(r, x) for x in (a, b, c)], dim=1), [ref] + others, device)
+
+
+def test_row_mae(device):
+    x, y = rnd(3, 16, 12, 1, seed=5), rnd(3, 16, 12, 1, seed=6)
+    check(lambda a, b: P.row_mae(a, b), lambda a, b: O.mae_single_input(a, b).reshape(-1), [x, y], device,
+          grad_mask=[False, True])
+
+
+def test_seg_loss_per_sample(device):
+    B, H, W = 3, 16, 12
+    t = torch.cat([_anat(B, H, W, 4, 7), torch.zeros(B, H, W, 1)], -1)
+    t[..., 4] = 1 - t[..., :4].sum(-1)
+    t[0, :3] = t[0, :3] * 0.5 + 0.1                      # fractional labels (rotated masks) go through the softmax too
+    p = torch.softmax(rnd(B, H, W, 5, seed=8), -1)
+    check(lambda a, b: P.seg_loss_per_sample(a, b, 4), lambda a, b: O.combined_dice_bce_perbatch(a, b, 4), [t, p], device,
+          grad_mask=[False, True])
+
+
+def test_row_dot(device):
+    w = torch.softmax(rnd(4, 3, seed=9), -1)
+    ls = [rnd(4, 1, seed=10), rnd(4, seed=11), rnd(4, 1, seed=12)]
+    check(lambda w_, a, b, c: P.row_dot(w_, [a, b, c]),
+          lambda w_, a, b, c: w_[:, 0:1] * a + w_[:, 1:2] * b.reshape(-1, 1) + w_[:, 2:3] * c, [w] + ls, device)
