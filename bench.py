@@ -46,13 +46,22 @@ class ConvTimer(object):
         timer = self
 
         def call(name, *args):
-            if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_wgrad', 'mmseg_conv2d_dgrad_parity'):
-                if name == 'mmseg_conv2d_dgrad_parity':
+            if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_wgrad', 'mmseg_conv2d_dgrad_parity',
+                                          'mmseg_conv2d_dgrad_parity_all'):
+                if name == 'mmseg_conv2d_dgrad_parity_all':
+                    (B, Ho, Wo, Cout, H, W, Cin, KH, KW, stride) = args[3:13]
+                    # the parity classes together touch every (output pixel, tap) pair of the strided convolution once
+                    flops = 2.0 * B * Ho * Wo * KH * KW * Cin * Cout
+                    nbytes = 4.0 * (B * Ho * Wo * Cout + KH * KW * Cin * Cout + B * H * W * Cin)
+                    kind = 'conv_fwd_kernel'
+                    shape = ('dgrad_parity_all', B, Ho, Wo, Cout, Cin, KH, KW, stride)
+                elif name == 'mmseg_conv2d_dgrad_parity':
                     (B, Ho, Wo, Cout, H, W, Cin, TH, TW, stride, ph, pw) = args[3:15]
                     hs, ws = (H - ph + stride - 1) // stride, (W - pw + stride - 1) // stride
                     flops = 2.0 * B * hs * ws * Cin * TH * TW * Cout     # exact taps of this parity class
                     nbytes = 4.0 * (B * Ho * Wo * Cout + TH * TW * Cin * Cout + B * hs * ws * Cin)
                     kind = 'conv_fwd_kernel'
+                    shape = ('dgrad_parity', B, Ho, Wo, Cout, Cin, TH, TW, stride)
                 elif name == 'mmseg_conv2d_fwd':
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[7:17]
                     transposed = args[21]
@@ -64,24 +73,40 @@ class ConvTimer(object):
                     # algorithmic bytes: every input element, weight and output element once
                     nbytes = 4.0 * (B * (H >> ups) * (W >> ups) * C1 + B * H * W * C2 + KH * KW * (C1 + C2) * Cout + B * Ho * Wo * Cout)
                     kind = 'conv_fwd_kernel'
+                    shape = ('dgrad_T' if transposed else 'fwd', B, H, W, C1, C2, Cout, KH, KW, 'ups' if ups else '')
                 else:
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[6:16]
                     flops = 2.0 * B * Ho * Wo * Cout * KH * KW * (C1 + C2)
                     ups = args[19]
                     nbytes = 4.0 * (B * (H >> ups) * (W >> ups) * C1 + B * H * W * C2 + KH * KW * (C1 + C2) * Cout + B * Ho * Wo * Cout)
                     kind = 'conv_wgrad_kernel'
+                    shape = ('wgrad', B, H, W, C1, C2, Cout, KH, KW, 'ups' if ups else '')
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 rc = timer._orig(name, *args)
                 e.record()
-                timer.records.append((kind, flops, nbytes, s, e))
+                timer.records.append((kind, flops, nbytes, s, e, shape))
                 return rc
             return timer._orig(name, *args)
         _native.call = call
 
+    def breakdown(self, steps):
+        """per-shape table (stderr): launches/step, ms/step, TFLOP/s -- where the convolution time of a step goes"""
+        agg = {}
+        for kind, flops, nbytes, s, e, shape in self.records:
+            d = agg.setdefault(shape, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e)
+            d[2] += flops
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        sys.stderr.write('%-60s %8s %9s %9s\n' % ('shape', 'n/step', 'ms/step', 'TFLOP/s'))
+        for shape, (n, ms, fl) in rows:
+            sys.stderr.write('%-60s %8.1f %9.3f %9.1f\n' % (' '.join(str(v) for v in shape), n / steps, ms / steps,
+                                                           fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0))
+
     def summary(self):
         out = {}
-        for kind, flops, nbytes, s, e in self.records:
+        for kind, flops, nbytes, s, e, _ in self.records:
             d = out.setdefault(kind, {'flops': 0.0, 'ms': 0.0, 'launches': 0, 'bytes': 0.0})
             d['flops'] += flops
             d['bytes'] += nbytes
@@ -158,6 +183,7 @@ def main():
     ap.add_argument('--l_mix', type=float, default=1.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
+    ap.add_argument('--conv-breakdown', action='store_true', help='per-shape convolution table on stderr')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -230,6 +256,9 @@ def main():
     dt = time.perf_counter() - t0
     timer.enabled = False
     _progress('timed region done: %.1f ms/step' % (1000.0 * dt / args.steps))
+    if args.conv_breakdown and rank == 0:
+        torch.cuda.synchronize()
+        timer.breakdown(args.steps)
     if world > 1:
         tmax = torch.tensor([dt], device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -56,6 +56,14 @@ int mmseg_conv2d_parity_taps(int K, int stride, int p);
 int mmseg_conv2d_wprep_parity(const float* w, float* out, int KH, int KW, int Cin, int Cout, int stride, int ph, int pw, void* stream);
 int mmseg_conv2d_dgrad_parity(const float* dy, const float* wt, float* dx, int B, int Ho, int Wo, int Cout, int H, int W, int Cin,
                               int TH, int TW, int stride, int ph, int pw, void* stream);
+/* data gradient of the discriminators' first layer (models/discriminator.py:24: 4x4, stride 2, valid; Cin = 1 or 4, Cout = 64):
+ * direct kernel, w in the Keras layout */
+int mmseg_conv2d_dgrad_s2k4_smallc(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                                   void* stream);
+/* all stride x stride parity classes of the data gradient in one batched launch; wt_all = the classes' sub-kernels from
+ * mmseg_conv2d_wprep_parity back to back in (ph, pw) raster order */
+int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* dx, int B, int Ho, int Wo, int Cout, int H, int W,
+                                  int Cin, int KH, int KW, int stride, void* stream);
 long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 /* dW[KH,KW,Cin,Cout] = sum over output pixels of im2col(x)^T * dy ; ws: mmseg_conv2d_wgrad_workspace floats */
 int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,

@@ -20,6 +20,7 @@
 // ds_read_b128 feeds four consecutive MFMAs; A and B use the same permutation so the sum is
 // unchanged.
 #include "common.hpp"
+#include <stdlib.h>
 
 struct ConvParams {
     const float* x1;
@@ -278,7 +279,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_of
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
+__device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bid, const int nblk) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_RPP = NT / 8, A_F4 = BM / A_RPP;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
     const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int ntn = (p.Cout + BN - 1) / BN;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int lb = xcd_remap(bid, nblk);
     const int mt = lb / ntn, n0 = (lb % ntn) * BN;
     // 2-D pixel tiles (TH x 16) when the output plane divides evenly: the 9 taps of a tile then re-read an L1-sized
     // halo patch instead of 9 disjoint row segments; otherwise BM consecutive pixels in raster order
@@ -460,6 +461,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
 }
 
 template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
+    conv_fast_body<BM, BN, WM, WN>(p, blockIdx.x, gridDim.x);
+}
+// up to 4 independent convolutions of one tile configuration in a single launch (blockIdx.y selects the problem): the
+// parity classes of a strided convolution's data gradient are each too small to fill 256 CUs
+struct ConvBatch { ConvParams p[4]; int nblk[4]; };
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_fast_batched_kernel(ConvBatch pb) {
+    const int z = blockIdx.y;
+    const int nb = pb.nblk[z];
+    if ((int)blockIdx.x >= nb) return;
+    conv_fast_body<BM, BN, WM, WN>(pb.p[z], blockIdx.x, nb);
+}
+template <int BM, int BN, int WM, int WN>
+static int launch_fast_batched(ConvBatch& pb, int n, hipStream_t st) {
+    int mx = 0;
+    for (int z = 0; z < n; ++z) {
+        const ConvParams& p = pb.p[z];
+        pb.nblk[z] = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+        if (pb.nblk[z] > mx) mx = pb.nblk[z];
+    }
+    for (int z = n; z < 4; ++z) pb.nblk[z] = 0;
+    hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+template <int BM, int BN, int WM, int WN>
 static int launch_fast(const ConvParams& p, hipStream_t st) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
     hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
@@ -562,6 +590,79 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
         return launch_fwd<64, 64, 2, 2>(p, vec, st);
     }
     return launch_fwd<128, 32, 4, 1>(p, vec, st);
+}
+
+// =====================================================================================
+// Data gradient of the discriminators' FIRST layer (4x4, stride 2, valid, Cin = 1 image channel or 4 mask channels,
+// Cout = 64): dx[y, x, ci] = sum_{kh = y mod 2 (+2), kw = x mod 2 (+2)} sum_co dy[(y-kh)/2, (x-kw)/2, co] * w[kh, kw, ci, co].
+// An N = Cin GEMM is hopeless on 32-wide MFMA tiles (0.5 TFLOP/s through the generic path); the op is a 64-term dot
+// product per tap, HBM/L2-bound on reading dy.  Mapping: 16 lanes own the 64 channels of a dy pixel (one coalesced 256-byte
+// read); such a group handles index (i, j) = the 2x2 input pixels (2i+ph, 2j+pw), which all read the SAME four dy pixels
+// (i-di, j-dj) with different taps (kh = ph + 2di, kw = pw + 2dj) -> every dy pixel is fetched 4 times instead of 16;
+// partial dots are reduced over the 16 lanes with 4 shuffles.  Weights (16 taps x Cin x 64) sit in LDS.
+// =====================================================================================
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_dgrad_s2k4_smallc_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                     float* __restrict__ dx, int B, int H, int W, int Ho, int Wo) {
+    constexpr int CO = 64;
+    __shared__ __attribute__((aligned(16))) float wl[16 * CIN * CO];
+    for (int i = threadIdx.x; i < 16 * CIN * CO / 4; i += 256)
+        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(w)[i];
+    __syncthreads();
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int Hi = (H + 1) >> 1, Wi = (W + 1) >> 1;
+    const long total = (long)B * Hi * Wi;
+    const long gidx = (long)blockIdx.x * 16 + grp;
+    const bool live = gidx < total;
+    const long gi = live ? gidx : 0;
+    const int b = (int)(gi / ((long)Hi * Wi));
+    const int r = (int)(gi - (long)b * Hi * Wi);
+    const int i = r / Wi, j = r - i * Wi;
+    float acc[2][2][CIN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) acc[a][c][ci] = 0.f;
+#pragma unroll
+    for (int di = 0; di < 2; ++di) {
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+            const int oy = i - di, ox = j - dj;
+            if (live && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (((size_t)b * Ho + oy) * Wo + ox) * CO + 4 * l16);
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                    for (int pw = 0; pw < 2; ++pw) {
+                        const int tap = (ph + 2 * di) * 4 + (pw + 2 * dj);
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[(tap * CIN + ci) * CO + 4 * l16]);
+                            acc[ph][pw][ci] += g[0] * wv[0] + g[1] * wv[1] + g[2] * wv[2] + g[3] * wv[3];
+                        }
+                    }
+            }
+        }
+    }
+    // reduce over the 16 lanes of the group; afterwards lane q < 4*CIN writes value q = (ph, pw, ci)
+    float mine = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                float v = acc[ph][pw][ci];
+                v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+                if (l16 == (ph * 2 + pw) * CIN + ci) mine = v;
+            }
+    if (live && l16 < 4 * CIN) {
+        const int q = l16 / CIN, ci = l16 - q * CIN;
+        const int y = 2 * i + (q >> 1), x = 2 * j + (q & 1);
+        if (y < H && x < W) dx[(((size_t)b * H + y) * W + x) * CIN + ci] = mine;
+    }
 }
 
 // =====================================================================================
@@ -1058,11 +1159,74 @@ int mmseg_conv2d_dgrad_parity(const float* dy, const float* wt, float* dx, int B
                            0, 0, 0, 0.f, 0, H, W, stride, stride, ph, pw, stream);
 }
 
+// dx [B,H,W,Cin] = data gradient of a 4x4 stride-2 'valid' convolution with Cin in {1, 4} and Cout = 64 (the first layer of
+// D_Image / D_Mask, models/discriminator.py:24); dy [B,Ho,Wo,64], w [4,4,Cin,64] in the Keras layout (no re-layout needed)
+int mmseg_conv2d_dgrad_s2k4_smallc(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                                   void* stream) {
+    if (Cout != 64 || (Cin != 1 && Cin != 4) || Ho != (H - 4) / 2 + 1 || Wo != (W - 4) / 2 + 1 || H < 4 || W < 4 ||
+        !aligned16(dy) || !aligned16(w))
+        return (int)hipErrorInvalidValue;
+    const long groups = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+    const dim3 grid((unsigned)((groups + 15) / 16)), block(256);
+    if (Cin == 1) hipLaunchKernelGGL(conv_dgrad_s2k4_smallc_kernel<1>, grid, block, 0, (hipStream_t)stream, dy, w, dx, B, H, W, Ho, Wo);
+    else hipLaunchKernelGGL(conv_dgrad_s2k4_smallc_kernel<4>, grid, block, 0, (hipStream_t)stream, dy, w, dx, B, H, W, Ho, Wo);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_conv2d_parity_taps(int K, int stride, int p);
+// All stride x stride parity classes in ONE launch.  `wt_all` holds the classes' sub-kernels back to back in (ph, pw)
+// raster order, class (ph, pw) being the TH(ph) x TW(pw) x Cout x Cin block written by mmseg_conv2d_wprep_parity
+// (TH(p) = mmseg_conv2d_parity_taps(KH, stride, p)); classes without taps or pixels are skipped (their dx stays as is:
+// the caller zero-fills dx when some class has no taps, i.e. when KH < stride or KW < stride).
+int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* dx, int B, int Ho, int Wo, int Cout, int H, int W,
+                                  int Cin, int KH, int KW, int stride, void* stream) {
+    if (stride != 2 || Cout % 32 != 0 || Cin % 4 != 0) return (int)hipErrorInvalidValue;
+    ConvBatch pb;
+    int n = 0;
+    long woff = 0, maxM = 0;
+    for (int ph = 0; ph < stride; ++ph)
+        for (int pw = 0; pw < stride; ++pw) {
+            const int TH = mmseg_conv2d_parity_taps(KH, stride, ph), TW = mmseg_conv2d_parity_taps(KW, stride, pw);
+            const int Hs = (H - ph + stride - 1) / stride, Ws = (W - pw + stride - 1) / stride;
+            const long wsz = (long)TH * TW * Cout * Cin;
+            if (TH > 0 && TW > 0 && Hs > 0 && Ws > 0) {
+                ConvParams& p = pb.p[n++];
+                p.oH = H; p.oW = W; p.osh = stride; p.osw = stride; p.ooh = ph; p.oow = pw;
+                p.x1 = dy; p.x2 = nullptr; p.w = nullptr; p.wt = wt_all + woff; p.bias = nullptr; p.y = dx; p.y2 = nullptr;
+                p.B = B; p.H = Ho; p.W = Wo; p.C1 = Cout; p.C2 = 0; p.H1 = Ho; p.W1 = Wo;
+                p.Ho = Hs; p.Wo = Ws; p.Cout = Cin; p.KH = TH; p.KW = TW; p.stride = 1;
+                p.pad_h = TH - 1; p.pad_w = TW - 1; p.ups = 0; p.transposed = 0; p.act = 0; p.alpha = 0.f;
+                p.M = B * Hs * Ws; p.K = TH * TW * Cout; p.nsplit1 = 0;
+                if (p.M > maxM) maxM = p.M;
+                if (((uintptr_t)p.wt & 15) != 0) return (int)hipErrorInvalidValue;
+            }
+            woff += wsz;
+        }
+    if (n == 0) return 0;
+    if (((uintptr_t)dy & 15) != 0 || (long)B * Ho * Wo * Cout * 4 >= (1L << 31) - 64) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const long tiles_big = ((maxM + 127) / 128) * ((Cin + 127) / 128) * n;
+    if (Cin > 64 && tiles_big >= 384) return launch_fast_batched<128, 128, 2, 2>(pb, n, st);
+    if (Cin > 32) {
+        const long tiles_mid = ((maxM + 127) / 128) * ((Cin + 63) / 64) * n;
+        if (tiles_mid >= 384) return launch_fast_batched<128, 64, 2, 2>(pb, n, st);
+        return launch_fast_batched<64, 64, 2, 2>(pb, n, st);
+    }
+    return launch_fast_batched<128, 32, 4, 1>(pb, n, st);
+}
+
 // number of floats of workspace mmseg_conv2d_wgrad needs for this geometry (0: writes dW directly)
 // number of pixel splits (slabs) of the weight gradient: enough blocks to fill the chip, at least 512 pixels each
+static int wgrad_target_blocks() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MMSEG_WGRAD_BLOCKS"); v = e ? atoi(e) : 4096; if (v < 1) v = 4096; }
+    return v;
+}
 static int wgrad_splits(long M, long K, int Cout) {
-    const long tiles = ((K + 127) / 128) * ((Cout + 63) / 64);
-    long S = (1024 + tiles - 1) / tiles;
+    const int bnt = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);          // the N tile the dispatcher below picks
+    const long tiles = ((K + 127) / 128) * ((Cout + bnt - 1) / bnt);
+    const long target = wgrad_target_blocks();
+    long S = (target + tiles - 1) / tiles;
     const long maxS = (M + 511) / 512;
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;

@@ -94,6 +94,31 @@ def _wprep_parity(w, KH, KW, Cin, Cout, stride, ph, pw, ntaps, wkey=None):
     return out
 
 
+def _wprep_parity_all(w, KH, KW, Cin, Cout, stride, taps, wkey=None):
+    """The sub-kernels of all stride x stride parity classes back to back in (ph, pw) raster order (the operand of
+    mmseg_conv2d_dgrad_parity_all); cached per weight version like _wprep."""
+    sizes = [taps[0][qh] * taps[1][qw] * Cin * Cout for qh in range(stride) for qw in range(stride)]
+    n = sum(sizes)
+    key = (wkey, w.data_ptr(), 'parity_all', stride)
+    ent = _wprep_cache.get(key) if wkey is not None else None
+    if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == n:
+        return ent[1]
+    if wkey is None:
+        out = _ws('wprep_parity_all', n, w.device)[:n]
+    else:
+        out = ent[1] if (ent is not None and ent[1].numel() == n) else torch.empty(n, dtype=torch.float32, device=w.device)
+    off = 0
+    for qh in range(stride):
+        for qw in range(stride):
+            sz = taps[0][qh] * taps[1][qw] * Cin * Cout
+            if sz:
+                N.call('mmseg_conv2d_wprep_parity', w, out[off:off + sz], KH, KW, Cin, Cout, stride, qh, qw)
+            off += sz
+    if wkey is not None:
+        _wprep_cache[key] = (_weight_version[0], out)
+    return out
+
+
 def _conv_fwd_raw(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, transposed,
                   act, alpha, nsplit1):
     # host-side shape checks: the kernel trusts these numbers
@@ -170,13 +195,16 @@ class _Conv2d(torch.autograd.Function):
             d1 = _new((B, H, W, C1), dy)
             d2 = _new((B, H, W, C2), dy) if C2 else None
             taps = [[N.call('mmseg_conv2d_parity_taps', k, stride, q) for q in range(stride)] for k in (KH, KW)] if tr else None
-            if tr and C2 == 0 and not ups and N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0) and min(taps[0] + taps[1]) > 0:
-                # strided convolution: one exact stride-1 launch per parity class of the input pixels
-                for qh in range(stride):
-                    for qw in range(stride):
-                        wp = _wprep_parity(w, KH, KW, Cin, Cout, stride, qh, qw, taps[0][qh] * taps[1][qw], ctx.wkey)
-                        N.call('mmseg_conv2d_dgrad_parity', g, wp, d1, B, Ho, Wo, Cout, H, W, Cin, taps[0][qh], taps[1][qw],
-                               stride, qh, qw)
+            if tr and stride == 2 and KH == 4 and KW == 4 and ph == 0 and pw == 0 and C2 == 0 and not ups and Cout == 64 and \
+                    Cin in (1, 4) and N.call('mmseg_conv2d_fast_path', 64, 0, 64, 0):
+                # first layer of a discriminator: N = Cin GEMM -> direct kernel
+                N.call('mmseg_conv2d_dgrad_s2k4_smallc', g, w, d1, B, H, W, Cin, Ho, Wo, Cout)
+            elif tr and stride == 2 and C2 == 0 and not ups and N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0) and \
+                    min(taps[0] + taps[1]) > 0:
+                # strided convolution: the parity classes of the input pixels, each an exact stride-1 convolution, batched
+                # into one launch (a single class does not fill the chip)
+                wp = _wprep_parity_all(w, KH, KW, Cin, Cout, stride, taps, ctx.wkey)
+                N.call('mmseg_conv2d_dgrad_parity_all', g, wp, d1, B, Ho, Wo, Cout, H, W, Cin, KH, KW, stride)
             else:
                 if N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, tr):
                     wf, wt = None, _wprep(w, KH, KW, Cin, Cout, 1, ctx.wkey)     # [Cin][flipped taps][Cout]
