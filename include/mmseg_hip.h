@@ -65,10 +65,11 @@ int mmseg_conv2d_dgrad_s2k4_smallc(const float* dy, const float* w, float* dx, i
 int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* dx, int B, int Ho, int Wo, int Cout, int H, int W,
                                   int Cin, int KH, int KW, int stride, void* stream);
 long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
-/* dW[KH,KW,Cin,Cout] = sum over output pixels of im2col(x)^T * dy ; ws: mmseg_conv2d_wgrad_workspace floats */
+/* dW[KH,KW,Cin,Cout] (+)= sum over output pixels of im2col(x)^T * dy (accumulate != 0 adds to dW: gradient arenas);
+ * ws: mmseg_conv2d_wgrad_workspace floats */
 int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
                        int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
-                       int pad_h, int pad_w, int ups, void* stream);
+                       int pad_h, int pad_w, int ups, int accumulate, void* stream);
 /* wt[kh][kw][co][ci] = w[KH-1-kh][KW-1-kw][ci][co]: the kernel of the data-gradient convolution */
 int mmseg_conv2d_wflip(const float* w, float* wt, int KH, int KW, int Cin, int Cout, void* stream);
 

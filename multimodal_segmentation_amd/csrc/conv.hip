@@ -876,7 +876,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(WgradParams q)
 // grid.y = number of slab groups (1 for the final pass).  Many slabs of a SMALL matrix (e.g. 1024 x 576 floats for the
 // 8 -> 8 layers) are reduced in two passes so that no thread walks more than ~8 slabs serially.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n, int S,
-                                                          int per_group) {
+                                                          int per_group, int accumulate) {
     __shared__ f32x4 sm[4][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const long i4 = ((long)blockIdx.x * 64 + cl) * 4;
@@ -892,22 +892,26 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     sm[sl][cl] = a;
     __syncthreads();
     if (sl == 0) {
-        const f32x4 t = sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl];
+        f32x4 t = sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl];
         float* o = out + (size_t)blockIdx.y * n;
-        if (i4 + 3 < n) *reinterpret_cast<f32x4*>(o + i4) = t;
-        else for (int e = 0; e < 4; ++e) if (i4 + e < n) o[i4 + e] = t[e];
+        if (i4 + 3 < n) {
+            if (accumulate) t += *reinterpret_cast<const f32x4*>(o + i4);
+            *reinterpret_cast<f32x4*>(o + i4) = t;
+        } else {
+            for (int e = 0; e < 4; ++e) if (i4 + e < n) o[i4 + e] = accumulate ? o[i4 + e] + t[e] : t[e];
+        }
     }
 }
 
 // dW = sum of S slabs of n floats (ws is clobbered: the first-level partial sums are written over its first slabs' tail)
-static void launch_slab_reduce(const float* ws, float* tmp, float* dw, long n, int S, hipStream_t st) {
+static void launch_slab_reduce(const float* ws, float* tmp, float* dw, long n, int S, int accumulate, hipStream_t st) {
     const unsigned nb = (unsigned)((n / 4 + 1 + 63) / 64);
     if (S > 64 && tmp != nullptr) {
         const int G = (S + 31) / 32;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb, G), dim3(256), 0, st, ws, tmp, n, S, 32);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb, 1), dim3(256), 0, st, (const float*)tmp, dw, n, G, G);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb, G), dim3(256), 0, st, ws, tmp, n, S, 32, 0);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb, 1), dim3(256), 0, st, (const float*)tmp, dw, n, G, G, accumulate);
     } else {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb, 1), dim3(256), 0, st, ws, dw, n, S, S);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb, 1), dim3(256), 0, st, ws, dw, n, S, S, accumulate);
     }
 }
 
@@ -1235,12 +1239,13 @@ static int wgrad_splits(long M, long K, int Cout) {
 long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     const long M = (long)B * Ho * Wo, K = (long)KH * KW * Cin;
     const long S = wgrad_splits(M, K, Cout);
-    return S == 1 ? 0 : (S + (S > 64 ? (S + 31) / 32 : 0)) * K * Cout;   // slabs (+ first-level partial sums)
+    return (S + (S > 64 ? (S + 31) / 32 : 0)) * K * Cout;   // slabs (+ first-level partial sums); one slab even for S = 1
+                                                            // (accumulating launches stage their single slab)
 }
 
 int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
                        int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
-                       int pad_h, int pad_w, int ups, void* stream) {
+                       int pad_h, int pad_w, int ups, int accumulate, void* stream) {
     WgradParams q;
     ConvParams& p = q.c;
     p.x1 = x1; p.x2 = x2; p.w = nullptr; p.wt = nullptr; p.bias = nullptr; p.y = nullptr; p.y2 = nullptr;
@@ -1258,14 +1263,15 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     float* tmp = (S > 64) ? ws + (size_t)S * KN : nullptr;
     int chunk = (p.M + S - 1) / S;
     chunk = (chunk + 31) / 32 * 32;
-    q.dy = dy; q.chunk = chunk; q.ws = S == 1 ? dw : ws;
+    const bool direct = S == 1 && !accumulate;      // a single slab that overwrites dW needs no staging
+    q.dy = dy; q.chunk = chunk; q.ws = direct ? dw : ws;
     hipStream_t st = (hipStream_t)stream;
     if (C1 == 8 && C2 == 0 && Cout == 8 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && !ups && Ho == H &&
         Wo == W && H % WG8_ROWS == 0 && W % WG8_COLS == 0 && S > 1 && aligned16(x1) && aligned16(dy)) {
         const int ntiles = B * (H / WG8_ROWS) * (W / WG8_COLS);
         const int nblk = ntiles < S ? ntiles : S;
         hipLaunchKernelGGL(conv_wgrad_c8_kernel, dim3(nblk), dim3(256), 0, st, x1, dy, ws, B, H, W, ntiles);
-        launch_slab_reduce(ws, tmp, dw, KN, nblk, st);
+        launch_slab_reduce(ws, tmp, dw, KN, nblk, accumulate, st);
         return MMSEG_CHECK_LAUNCH();
     }
     const bool vec = (C1 % 4 == 0) && (C2 % 4 == 0) && aligned16(x1) && (C2 == 0 || aligned16(x2));
@@ -1278,8 +1284,8 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     else if (fast) rc = launch_wgrad_fast<128, 32, 4, 1>(q, S, st);
     else if (Cout > 32) rc = launch_wgrad<128, 64, 2, 2>(q, S, vec, st);
     else rc = launch_wgrad<128, 32, 4, 1>(q, S, vec, st);
-    if (rc != 0 || S == 1) return rc;
-    launch_slab_reduce(ws, tmp, dw, KN, S, st);
+    if (rc != 0 || direct) return rc;
+    launch_slab_reduce(ws, tmp, dw, KN, S, accumulate, st);
     return MMSEG_CHECK_LAUNCH();
 }
 

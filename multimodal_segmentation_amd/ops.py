@@ -183,12 +183,11 @@ class _Conv2d(torch.autograd.Function):
             ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', M, Cout), dy.device)
             N.call('mmseg_colsum', g, ctx.bgrad, ws, M, Cout, 1.0, 1)
         if ctx.wgrad is not None:
-            dw = _ws('dw_tmp', w.numel(), dy.device)[:w.numel()]
             need = N.call('mmseg_conv2d_wgrad_workspace', B, Ho, Wo, C1 + C2, Cout, KH, KW)
             ws = _ws('wgrad', need, dy.device)
-            N.call('mmseg_conv2d_wgrad', x1, x2, g, dw, ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride,
-                   ph, pw, ups)
-            _accumulate(ctx.wgrad.view(-1), dw)
+            # accumulates straight into the gradient-arena view (the final slab reduction adds to it)
+            N.call('mmseg_conv2d_wgrad', x1, x2, g, ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
+                   stride, ph, pw, ups, 1)
         if need_x1 or (x2 is not None and need_x2):
             Cin = C1 + C2
             tr = 1 if stride > 1 else 0

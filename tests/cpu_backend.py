@@ -86,11 +86,15 @@ def conv2d_wgrad_workspace(B, Ho, Wo, Cin, Cout, KH, KW):
     return 0
 
 
-def conv2d_wgrad(x1, x2, dy, dw, ws, ws_floats, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups):
+def conv2d_wgrad(x1, x2, dy, dw, ws, ws_floats, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, accumulate):
     xin = _logical_input(x1, x2, B, H, W, C1, C2, ups).permute(0, 3, 1, 2)
     g = dy.reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
     gw = torch.nn.grad.conv2d_weight(xin, (Cout, C1 + C2, KH, KW), g, stride=stride, padding=(ph, pw))
-    dw.copy_(gw.permute(2, 3, 1, 0).reshape(dw.shape))
+    gw = gw.permute(2, 3, 1, 0).reshape(dw.shape)
+    if accumulate:
+        dw.add_(gw)
+    else:
+        dw.copy_(gw)
     return 0
 
 

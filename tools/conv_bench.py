@@ -52,7 +52,7 @@ def main():
         wp2 = torch.empty_like(wt)
         N.call('mmseg_conv2d_wprep', w, wp2, k, k, Cin, Cout, 1)
         t_d = timeit(lambda: N.call('mmseg_conv2d_fwd', y, None, wt, wp2, None, dx, None, B, H, H, Cout, 0, H, H, Cin, k, k, 1, p, p, 0, 0, 0, 0.0, 0))
-        t_w = timeit(lambda: N.call('mmseg_conv2d_wgrad', x, None, y, dw, ws, ws.numel(), B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0))
+        t_w = timeit(lambda: N.call('mmseg_conv2d_wgrad', x, None, y, dw, ws, ws.numel(), B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0, 0))
         if os.environ.get('CONV_BENCH_COLS') == 'wgrad':
             print('%d^2_%d->%d_k%d %6.1f %6.3f' % (H, Cin, Cout, k, flops / t_w / 1e9, t_w))
             continue

@@ -17,5 +17,5 @@ for _ in range(5):
     if mode == 'fwd':
         N.call('mmseg_conv2d_fwd', x, None, w, wp, None, y, None, B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0, 0, 0, 0.0, 0)
     else:
-        N.call('mmseg_conv2d_wgrad', x, None, y, dw, ws, ws.numel(), B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0)
+        N.call('mmseg_conv2d_wgrad', x, None, y, dw, ws, ws.numel(), B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0, 0)
 torch.cuda.synchronize()
