@@ -332,33 +332,30 @@ class DAFNetExecutor(Executor):
 
     # ---- fake pools, generated in `predict` mode and kept on the device ---------------------------------------------
     def mask_pools(self, x1, x2):
-        """dafnet_executor.py:524-543 -> (pool of 2B fake masks for modality 1, same for modality 2)"""
+        """dafnet_executor.py:524-543 -> (pool of 2B fake masks for modality 1, same for modality 2).  Inference mode has
+        no batch statistics, so the two fuser directions and the four segmentations run as one batched call each."""
         m, nm = self.model, self.conf.num_masks
         fake_s1 = m.Encoders_Anatomy[0].predict(x1)
         fake_s2 = m.Encoders_Anatomy[1].predict(x2)
-        fake_m1 = m.Segmentor.predict(fake_s1)
-        s2_def, _ = m.Anatomy_Fuser.predict([fake_s2, fake_s1])
-        fake_m1_from_s2 = m.Segmentor.predict(s2_def)
-        pool1 = torch.cat([fake_m1[..., 0:nm], fake_m1_from_s2[..., 0:nm]], 0).contiguous()
-        fake_m2 = m.Segmentor.predict(fake_s2)
-        s1_def, _ = m.Anatomy_Fuser.predict([fake_s1, fake_s2])
-        fake_m2_from_s1 = m.Segmentor.predict(s1_def)
-        pool2 = torch.cat([fake_m2[..., 0:nm], fake_m2_from_s1[..., 0:nm]], 0).contiguous()
-        return pool1, pool2
+        B = fake_s1.shape[0]
+        sd = m.Anatomy_Fuser.predict([torch.cat([fake_s2, fake_s1], 0), torch.cat([fake_s1, fake_s2], 0)])[0]
+        s2_def, s1_def = sd[:B], sd[B:]
+        masks = m.Segmentor.predict(torch.cat([fake_s1, s2_def, fake_s2, s1_def], 0))[..., 0:nm].contiguous()
+        return masks[:2 * B], masks[2 * B:]      # [m(s1); m(s2_def)], [m(s2); m(s1_def)]
 
     def image_pools(self, x1, x2, eps1=None, eps2=None):
-        """dafnet_executor.py:555-575 -> (pool of 3B fake images for modality 1, same for modality 2)"""
+        """dafnet_executor.py:555-575 -> (pool of 3B fake images for modality 1, same for modality 2); the six decodings
+        are one batched call"""
         m = self.model
         s1 = m.Encoders_Anatomy[0].predict(x1)
         s2 = m.Encoders_Anatomy[1].predict(x2)
-        s1_def = m.Anatomy_Fuser.predict([s1, s2])[0]
-        s2_def = m.Anatomy_Fuser.predict([s2, s1])[0]
+        B = s1.shape[0]
+        sd = m.Anatomy_Fuser.predict([torch.cat([s1, s2], 0), torch.cat([s2, s1], 0)])[0]
+        s1_def, s2_def = sd[:B], sd[B:]
         z1, _ = m.Enc_Modality.predict([s1, x1], eps=eps1)
         z2, _ = m.Enc_Modality.predict([s2, x2], eps=eps2)
-        dec = m.Decoder.predict
-        y1 = torch.cat([dec([s1, z1]), dec([s2_def, z1]), dec([s1_def, z1])], 0)
-        y2 = torch.cat([dec([s2, z2]), dec([s1_def, z2]), dec([s2_def, z2])], 0)
-        return y1, y2
+        ys = m.Decoder.predict([torch.cat([s1, s2_def, s1_def, s2, s1_def, s2_def], 0), torch.cat([z1, z1, z1, z2, z2, z2], 0)])
+        return ys[:3 * B], ys[3 * B:]
 
     def _sample(self, pool, batch_size):
         """utils.data_utils.sample: np.random.choice(len, size, replace=False), gathered on the device"""

@@ -100,10 +100,9 @@ class MMSDNetExecutor(DAFNetExecutor):
         """mmsdnet_executor.py:318-324 -> 4B fake masks"""
         m, nm = self.model, self.conf.num_masks
         fake_s = [m.Encoders_Anatomy[0].predict(x1), m.Encoders_Anatomy[1].predict(x2)]
-        fake_m = [m.Segmentor.predict(s) for s in fake_s]
         s1_def, s1_fused = m.Anatomy_Fuser.predict(fake_s)
-        fake_m += [m.Segmentor.predict(s) for s in [s1_def, s1_fused]]
-        return torch.cat(fake_m, 0)[..., 0:nm].contiguous()
+        # inference-mode BatchNorm has no batch statistics: the four segmentations are one batched call
+        return m.Segmentor.predict(torch.cat(fake_s + [s1_def, s1_fused], 0))[..., 0:nm].contiguous()
 
     def train_batch_mask_discriminator(self, epoch_loss):
         nm = self.conf.num_masks

@@ -123,33 +123,27 @@ class DAFNet(MMSDNet):
                     s2 = ops.ste_replace(s2, teacher_s[1])
                 z1, kl1 = self.Enc_Modality(s1, x1, eps=eps[0])
                 z2, kl2 = self.Enc_Modality(s2, x2, eps=eps[1])
-                # segment
+                # segment (BatchNorm batch statistics per call: these stay separate calls)
                 m1 = self.Segmentor(s1, training=training)
                 m2 = self.Segmentor(s2, training=training)
-                # decoder
-                y1 = self.Decoder(s1, z1)
-                y2 = self.Decoder(s2, z2)
-                # GANs
-                adv_m = lambda m: self.D_Mask(ops.slice_channels(m, 0, nm))
-                adv_m1, adv_m2 = adv_m(m1), adv_m(m2)
-                adv_y1 = self.D_Image1(y1)
-                adv_y2 = self.D_Image2(y2)
-                # deform and fuse
-                s1_def, _ = self.Anatomy_Fuser(s1, s2)
-                s2_def, _ = self.Anatomy_Fuser(s2, s1)
-                # segment
+                # deform and fuse: both directions in one batched call (per-sample component)
+                sd, _ = self.Anatomy_Fuser(ops.cat_batch([s1, s2]), ops.cat_batch([s2, s1]))
+                s1_def, s2_def = ops.split_batch(sd, 2)
                 m2_s1_def = self.Segmentor(s1_def, training=training)
                 m1_s2_def = self.Segmentor(s2_def, training=training)
-                # decoder (cross-reconstruction)
-                y2_s1_def = self.Decoder(s1_def, z2)
-                y1_s2_def = self.Decoder(s2_def, z1)
-                # GANs
-                adv_m2_s1_def, adv_m1_s2_def = adv_m(m2_s1_def), adv_m(m1_s2_def)
-                adv_y2_s1_def = self.D_Image2(y2_s1_def)
-                adv_y1_s2_def = self.D_Image1(y1_s2_def)
-                # Z-Regressor: Decoder then Enc_Modality_mu (dafnet.py:336-350)
-                z1_rec = self.Enc_Modality(s1, self.Decoder(s1, z1_input), mu_only=True)
-                z2_rec = self.Enc_Modality(s2, self.Decoder(s2, z2_input), mu_only=True)
+                # decoder: reconstructions, cross-reconstructions and the Z-regressor's decodings (dafnet.py:336-350) are six
+                # independent per-sample calls -> one batch of 6B
+                ys = self.Decoder(ops.cat_batch([s1, s2, s2_def, s1_def, s1, s2]),
+                                  ops.cat_batch([z1, z2, z1, z2, z1_input, z2_input]))
+                y1, y2, y1_s2_def, y2_s1_def, y1_zin, y2_zin = ops.split_batch(ys, 6)
+                # GANs (frozen discriminators, no batch statistics): one call per discriminator
+                adv_m1, adv_m2, adv_m1_s2_def, adv_m2_s1_def = ops.split_batch(
+                    self.D_Mask(ops.cat_batch([ops.slice_channels(m, 0, nm) for m in (m1, m2, m1_s2_def, m2_s1_def)])), 4)
+                adv_y1, adv_y1_s2_def = ops.split_batch(self.D_Image1(ops.cat_batch([y1, y1_s2_def])), 2)
+                adv_y2, adv_y2_s1_def = ops.split_batch(self.D_Image2(ops.cat_batch([y2, y2_s1_def])), 2)
+                # Z-Regressor: Enc_Modality_mu of the decodings of the sampled z
+                z1_rec = self.Enc_Modality(s1, y1_zin, mu_only=True)
+                z2_rec = self.Enc_Modality(s2, y2_zin, mu_only=True)
             all_outputs = [m1, m2, m1_s2_def, m2_s1_def] if supervised else [m1, m1_s2_def]
             all_outputs += [adv_m1, adv_m2, adv_m1_s2_def, adv_m2_s1_def] + \
                            [y1, y2, y1_s2_def, y2_s1_def] + \

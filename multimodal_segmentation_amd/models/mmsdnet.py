@@ -71,7 +71,9 @@ class MMSDNet(BaseNet):
     def _d_trainer(self, D, name, lr):
         """Model([real, fake], [D(real), D(fake)]) compiled with Adam / 'mse' (mmsdnet.py:70-77)"""
         def graph(ins, training=True):
-            real, fake = ins
+            real, fake = ins                      # no batch statistics in D: real and fake go through as one batch
+            if real.shape[0] == fake.shape[0]:
+                return ops.split_batch(D(ops.cat_batch([real, fake]), training=training), 2)
             return [D(real, training=training), D(fake, training=training)]
         specs = [OutputSpec(D.name, 'mse', 1.0), OutputSpec(D.name, 'mse', 1.0)]
         return Trainer(name, graph, specs, [D], nn.Adam(lr), regularised=[D])
@@ -118,8 +120,6 @@ class MMSDNet(BaseNet):
                 s_list = [self.Encoders_Anatomy[i](x_list[i], training=training) for i in range(2)]
                 z_list = [self.Enc_Modality(s_list[i], x_list[i], eps=eps[i]) for i in range(2)]
                 m1, m2 = [self.Segmentor(s, training=training) for s in s_list]
-                adv = lambda m: self.D_Mask(ops.slice_channels(m, 0, nm))
-                rec_x_list = [self.Decoder(s_list[i], z_list[i][0]) for i in range(2)]
                 s1_def, s1_fused = self.Anatomy_Fuser(s_list[0], s_list[1])
                 s2_def, s2_fused = self.Anatomy_Fuser(s_list[1], s_list[0])
                 fused_seg = [self.Segmentor(s, training=training) for s in [s1_def, s1_fused, s2_def, s2_fused]]
@@ -127,11 +127,13 @@ class MMSDNet(BaseNet):
                     m_list = [m1, m2] + fused_seg
                 else:
                     m_list = [m1] + fused_seg[2:]               # masks only for modality 1 (mmsdnet.py:107,116)
-                adv_m_list = [adv(m) for m in [m1, m2]] + [adv(m) for m in fused_seg]
+                # the frozen discriminator and the decoder have no batch statistics: six calls each -> one batched call
+                adv_m_list = ops.split_batch(self.D_Mask(ops.cat_batch([ops.slice_channels(m, 0, nm) for m in [m1, m2] + fused_seg])), 6)
                 z_s1def = [self.Enc_Modality(s, x_list[1], eps=eps[2 + i]) for i, s in enumerate([s1_def, s1_fused])]
-                rec_x_list += [self.Decoder(s, z_s1def[i][0]) for i, s in enumerate([s1_def, s1_fused])]
                 z_s2def = [self.Enc_Modality(s, x_list[0], eps=eps[4 + i]) for i, s in enumerate([s2_def, s2_fused])]
-                rec_x_list += [self.Decoder(s, z_s2def[i][0]) for i, s in enumerate([s2_def, s2_fused])]
+                rec_x_list = ops.split_batch(self.Decoder(
+                    ops.cat_batch(s_list + [s1_def, s1_fused, s2_def, s2_fused]),
+                    ops.cat_batch([z_list[0][0], z_list[1][0], z_s1def[0][0], z_s1def[1][0], z_s2def[0][0], z_s2def[1][0]])), 6)
                 diverg = [z_list[i][1] for i in range(2)] + [z_s1def[i][1] for i in range(2)] + [z_s2def[i][1] for i in range(2)]
             return m_list + adv_m_list + rec_x_list + diverg
         return graph

@@ -409,6 +409,9 @@ def softmax_round(x):
 # ------------------------------------------------------------------------------------------------------
 # dense
 # ------------------------------------------------------------------------------------------------------
+_DENSE_ROWS = 32
+
+
 class _Dense(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, w, bias, act, alpha, wgrad, bgrad):
@@ -417,8 +420,10 @@ class _Dense(torch.autograd.Function):
         K2, Nn = w.shape
         assert K == K2, 'dense: input has %d features, kernel expects %d' % (K, K2)
         y = _new((R, Nn), x)
-        ws = _ws('dense', N.call('mmseg_dense_workspace_floats', R, K, Nn), x.device)
-        N.call('mmseg_dense_fwd', x, w, bias, y, ws, R, K, Nn, ACT[act], float(alpha))
+        for r0 in range(0, R, _DENSE_ROWS):          # the kernels keep <= 32 rows in registers: larger batches go in row groups
+            r = min(_DENSE_ROWS, R - r0)
+            ws = _ws('dense', N.call('mmseg_dense_workspace_floats', r, K, Nn), x.device)
+            N.call('mmseg_dense_fwd', x[r0:r0 + r], w, bias, y[r0:r0 + r], ws, r, K, Nn, ACT[act], float(alpha))
         ctx.act, ctx.alpha = ACT[act], alpha
         ctx.w, ctx.wgrad, ctx.bgrad = w, wgrad, bgrad
         ctx.save_for_backward(x, y if ACT[act] else None)
@@ -439,11 +444,15 @@ class _Dense(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _new(x.shape, x)
-            N.call('mmseg_dense_dgrad', g, w, dx, R, K, Nn)
+            for r0 in range(0, R, _DENSE_ROWS):
+                r = min(_DENSE_ROWS, R - r0)
+                N.call('mmseg_dense_dgrad', g[r0:r0 + r], w, dx[r0:r0 + r], r, K, Nn)
         if ctx.wgrad is not None:
             dw = _ws('dw_tmp', w.numel(), x.device)[:w.numel()]
-            N.call('mmseg_dense_wgrad', x, g, dw, R, K, Nn)
-            _accumulate(ctx.wgrad.view(-1), dw)
+            for r0 in range(0, R, _DENSE_ROWS):
+                r = min(_DENSE_ROWS, R - r0)
+                N.call('mmseg_dense_wgrad', x[r0:r0 + r], g[r0:r0 + r], dw, r, K, Nn)
+                _accumulate(ctx.wgrad.view(-1), dw)
         if ctx.bgrad is not None:
             ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', R, Nn), x.device)
             N.call('mmseg_colsum', g, ctx.bgrad, ws, R, Nn, 1.0, 1)
@@ -881,6 +890,19 @@ def affine_gather(data, rows, mat, order=1):
     out = _new((B,) + tuple(data.shape[1:]), data)
     N.call('mmseg_affine_gather', data, rows, _c(mat), out, B, data.shape[1], data.shape[2], data.shape[3], int(order))
     return out
+
+
+def cat_batch(tensors):
+    """Stack independent calls of a per-sample component on the batch axis (pure data movement; autograd hands every
+    producer its slice of the gradient).  Components without batch statistics -- discriminators, FiLM / SPADE decoders,
+    the anatomy fuser, inference-mode BatchNorm -- give identical per-sample results, with 1/n of the launches and
+    GEMMs large enough to fill the chip."""
+    return torch.cat([_c(t) for t in tensors], dim=0)
+
+
+def split_batch(t, n):
+    """inverse of cat_batch for n equal parts"""
+    return list(torch.chunk(t, n, dim=0))
 
 
 class _SteReplace(torch.autograd.Function):
