@@ -1223,7 +1223,7 @@ int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* d
 // number of pixel splits (slabs) of the weight gradient: enough blocks to fill the chip, at least 512 pixels each
 static int wgrad_target_blocks() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MMSEG_WGRAD_BLOCKS"); v = e ? atoi(e) : 4096; if (v < 1) v = 4096; }
+    if (v < 0) { const char* e = getenv("MMSEG_WGRAD_BLOCKS"); v = e ? atoi(e) : 3072; if (v < 1) v = 3072; }
     return v;
 }
 static int wgrad_splits(long M, long K, int Cout) {

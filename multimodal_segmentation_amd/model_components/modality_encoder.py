@@ -32,15 +32,16 @@ class ModalityEncoder(nn.Model):
         self.finalize(rng)
         self.output_shape = [(None, conf.num_z), (None, 1)]
 
-    def _mean_logvar(self, s, x):
+    def _mean_logvar(self, s, x, want_logvar=True):
         l = nn.conv(self, 'c0', s, stride=2, padding='valid', act='leaky', alpha=0.3, x2=x)
         for i in (1, 2, 3):
             l = nn.conv(self, 'c%d' % i, l, stride=2, padding='valid', act='leaky', alpha=0.3)
         l = nn.dense(self, 'd0', l.reshape(l.shape[0], -1), act='leaky', alpha=0.3)
-        return nn.dense(self, 'z_mean', l), nn.dense(self, 'z_log_var', l)
+        # Enc_Modality_mu is the same network cut at z_mean (dafnet.py:126): the log-variance head is not evaluated there
+        return nn.dense(self, 'z_mean', l), (nn.dense(self, 'z_log_var', l) if want_logvar else None)
 
     def forward(self, s, x, training=False, eps=None, mu_only=False):
-        z_mean, z_log_var = self._mean_logvar(s, x)
+        z_mean, z_log_var = self._mean_logvar(s, x, want_logvar=not mu_only)
         if mu_only:
             return z_mean
         if eps is None:     # K.random_normal inside the graph (sdnet_utils.py:20): drawn on the host like z samples

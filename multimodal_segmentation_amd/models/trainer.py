@@ -76,6 +76,9 @@ class Trainer(object):
         assert len(targets) == len(self.specs), '%s: %d targets for %d outputs' % (self.name, len(targets), len(self.specs))
         for m in self.train_models:
             m.zero_grad_own()
+        # data parallel: arenas are all-reduced as soon as their last gradient kernel is queued (overlap with backward);
+        # models that also receive regulariser gradients after the backward pass are reduced at the end
+        tracker = dp.begin(self.train_models, defer=[d for d in self.regularised if d in self.train_models])
         with torch.enable_grad():
             outs = self.graph_fn(ins, **graph_kw)
             assert len(outs) == len(self.specs)
@@ -90,7 +93,7 @@ class Trainer(object):
         for d in self.regularised:
             for loss in d.regulariser_losses(accumulate_grad=d in self.train_models):
                 terms.append((1.0, loss))
-        dp.allreduce_gradients(self.train_models)
+        dp.finish(tracker)
         self.optimizer.step(self.train_models)
         hist.record('loss', nn_total(terms))
         self.last_outputs = [o.detach() for o in outs]

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .parallel import dp
 
 _DEVICE = None
 
@@ -100,7 +101,12 @@ class Param(object):
 
     def g(self):
         """Gradient view to accumulate into, or None when the owning model is frozen / not recording."""
-        return self.grad if (self.trainable and self.owner.trainable and torch.is_grad_enabled()) else None
+        if not (self.trainable and self.owner.trainable and torch.is_grad_enabled()):
+            return None
+        tr = dp.current_tracker()
+        if tr is not None:                 # data parallel: count the launches that will accumulate into this arena
+            tr.register(self.owner)
+        return self.grad
 
 
 class Model(object):
@@ -144,6 +150,7 @@ class Model(object):
             if p.trainable:
                 p.data = self.arena[p.offset:p.offset + p.numel].view(p.shape)
                 p.grad = self.grad_arena[p.offset:p.offset + p.numel].view(p.shape)
+                p.grad._owner = self           # lets the autograd Functions report 'gradient queued' to the DP tracker
             else:
                 p.data = self.state_arena[p.offset:p.offset + p.numel].view(p.shape)
         self.device = device

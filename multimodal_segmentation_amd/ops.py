@@ -8,6 +8,7 @@ layout (conv HWIO, dense [in, out]).
 import torch
 
 from . import _native as N
+from .parallel import dp
 
 ACT = {None: 0, 'linear': 0, 'relu': 1, 'leaky': 2, 'tanh': 3}
 BN_EPS = 1e-3        # keras BatchNormalization default
@@ -134,6 +135,18 @@ def _conv_fwd_raw(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH,
            ups, transposed, act, float(alpha), nsplit1)
 
 
+def _grad_done(*grads):
+    """Tell the data-parallel tracker that the launches accumulating into these gradient-arena views have been queued
+    (parallel/dp.py: the arena's all-reduce starts when its last accumulation is in the stream)."""
+    tr = dp.current_tracker()
+    if tr is None:
+        return
+    for t in grads:
+        owner = getattr(t, '_owner', None) if t is not None else None
+        if owner is not None:
+            tr.done(owner)
+
+
 def _accumulate(dst, src):
     """dst += src (weight-gradient accumulation into the gradient arena)."""
     N.call('mmseg_axpby', dst, src, dst, dst.numel(), 1.0, 1.0)
@@ -188,6 +201,7 @@ class _Conv2d(torch.autograd.Function):
             # accumulates straight into the gradient-arena view (the final slab reduction adds to it)
             N.call('mmseg_conv2d_wgrad', x1, x2, g, ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
                    stride, ph, pw, ups, 1)
+        _grad_done(ctx.wgrad, ctx.bgrad)
         if need_x1 or (x2 is not None and need_x2):
             Cin = C1 + C2
             tr = 1 if stride > 1 else 0
@@ -269,6 +283,7 @@ class _BatchNormTrain(torch.autograd.Function):
             _accumulate(ctx.ggrad, dgamma)
         if ctx.bgrad is not None:
             _accumulate(ctx.bgrad, dbeta)
+        _grad_done(ctx.ggrad, ctx.bgrad)
         return (dx,) + (None,) * 8
 
 
@@ -456,6 +471,7 @@ class _Dense(torch.autograd.Function):
         if ctx.bgrad is not None:
             ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', R, Nn), x.device)
             N.call('mmseg_colsum', g, ctx.bgrad, ws, R, Nn, 1.0, 1)
+        _grad_done(ctx.wgrad, ctx.bgrad)
         return (dx,) + (None,) * 7
 
 

@@ -2,10 +2,13 @@
 
 The path shards by independent slice pairs: every rank holds a full replica of the weights and processes its own
 batch; the only exchanges are
-  (i)  an all-reduce (mean) of each trainer's gradient arenas after its backward pass -- the arenas are flat,
-       16-byte aligned fp32 buffers (nn.Model.grad_arena), one collective per model, largest ~119 MB (shared UNet
-       up path), launched on a side stream as soon as the backward pass has been queued so that the collective of
-       model k overlaps the Adam kernels of the models already reduced;
+  (i)  an all-reduce (mean) of each trainer's gradient arenas -- flat, 16-byte aligned fp32 buffers
+       (nn.Model.grad_arena), one collective per component model, largest ~119 MB (shared UNet up path) -- OVERLAPPED
+       WITH THE BACKWARD PASS: every kernel launch that accumulates into an arena is counted in the forward pass
+       (GradTracker.register, from nn.Param.g) and un-counted when its backward has been queued (GradTracker.done, from
+       the autograd Functions of ops.py); when a model's count returns to zero its arena is final and its all-reduce is
+       issued at once (async: RCCL runs it on its own stream behind the kernels queued so far) while the backward pass
+       of the remaining models (the decoder / segmentor finish first, the encoders last) keeps the compute stream busy;
   (ii) an all-reduce (sum) of the 2x8 batch-global class sums of the swapped-argument BCE (costs.py:77-79 of the
        reference computes its class weights over the whole batch), so the loss equals the single-device loss on
        the global batch;
@@ -42,6 +45,71 @@ def class_sum_hook():
     def hook(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return hook
+
+
+_tracker = [None]
+
+
+def current_tracker():
+    return _tracker[0]
+
+
+class GradTracker(object):
+    """Issues the all-reduce of a model's gradient arena as soon as the last kernel accumulating into it has been queued."""
+
+    def __init__(self, models, defer=()):
+        self.models = list(models)
+        self.pending = {id(m): 0 for m in self.models}
+        self.used = set()
+        self.defer = set(id(m) for m in defer)      # arenas that still receive gradients after backward (regularisers)
+        self.fired = set()
+        self.works = []
+
+    def register(self, owner):
+        k = id(owner)
+        if k in self.pending:
+            self.pending[k] += 1
+            self.used.add(k)
+
+    def done(self, owner):
+        k = id(owner)
+        if k not in self.pending:
+            return
+        self.pending[k] -= 1
+        if self.pending[k] == 0 and k not in self.defer and k not in self.fired:
+            self._fire(owner)
+
+    def _fire(self, m):
+        self.fired.add(id(m))
+        self.works.append((m, dist.all_reduce(m.grad_arena, op=dist.ReduceOp.SUM, async_op=True)))
+
+    def finish(self):
+        """reduce whatever has not been reduced yet (in model order: identical on every rank), wait, average"""
+        _state['last_overlapped'] = len(self.works)     # collectives issued during the backward pass
+        for m in self.models:
+            if id(m) in self.used and id(m) not in self.fired:
+                self._fire(m)
+        _state['last_collectives'] = len(self.works)
+        from .. import ops
+        ws = float(dist.get_world_size())
+        for m, w in self.works:
+            w.wait()
+            ops.axpby(m.grad_arena, m.grad_arena, 1.0 / ws, 0.0, out=m.grad_arena)
+
+
+def begin(models, defer=()):
+    """start tracking one trainer step; returns None when data parallelism is off"""
+    if not enabled():
+        return None
+    _tracker[0] = GradTracker(models, defer)
+    return _tracker[0]
+
+
+def finish(tracker):
+    if tracker is None:
+        return
+    _tracker[0] = None
+    tracker.finish()
 
 
 def allreduce_gradients(models):

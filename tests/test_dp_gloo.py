@@ -39,6 +39,15 @@ def _build():
 
 
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except BaseException as exc:          # surface the failure instead of letting the parent wait for its timeout
+        import traceback
+        q.put((rank, 'error', traceback.format_exc(), repr(exc)))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -53,6 +62,7 @@ def _worker(rank, world, port, q):
     # ---- discriminator step: must equal the single-process step on the global batch --------------------------
     h = model.D_Mask_trainer.fit([d['dm_m1'][sl], d['dm_m2'][sl]], [1.0, 0.0])
     dm_after = model.D_Mask.arena.clone()
+    assert dp._state['last_overlapped'] == 0 and dp._state['last_collectives'] == 1     # regularised arena: reduced at the end
     # ---- generator step: replicas stay in sync, class sums are global -----------------------------------------
     ones = np.ones((1, 1), np.float32)
     model.supervised_trainer.fit([d['x1'][sl], d['x2'][sl], d['z1'][sl], d['z2'][sl]],
@@ -60,6 +70,8 @@ def _worker(rank, world, port, q):
                                  [d['x1'][sl], d['x2'][sl], d['x1'][sl], d['x2'][sl]] + [ones] * 4 +
                                  [np.zeros(1, np.float32)] * 2 + [d['z1'][sl], d['z2'][sl]],
                                  eps=[d['eps1'][sl], d['eps2'][sl]])
+    # every generator arena was all-reduced while the backward pass was still being queued (overlap), none at the end
+    assert dp._state['last_overlapped'] == len(gens) == dp._state['last_collectives'], dp._state
     sig = torch.cat([m.arena.double().sum().reshape(1) for m in gens])
     gathered = [torch.zeros_like(sig) for _ in range(world)]
     dist.all_gather(gathered, sig)
@@ -76,7 +88,10 @@ def test_dp_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=800) for _ in range(2)], key=lambda r: r[0])
+    res = [q.get(timeout=800) for _ in range(2)]
+    for r in res:
+        assert r[1] != 'error' if isinstance(r[1], str) else True, r[2]
+    res = sorted(res, key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

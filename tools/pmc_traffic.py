@@ -17,7 +17,7 @@ def load(d):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0].replace('void ', '')
-        fam = 'conv_fwd' if k.startswith(('conv_fast_kernel', 'conv_fwd_kernel', 'conv_direct_kernel')) else \
+        fam = 'conv_fwd' if k.startswith(('conv_fast_kernel', 'conv_fast_batched_kernel', 'conv_fwd_kernel', 'conv_direct_kernel')) else \
               ('conv_wgrad' if k.startswith('conv_wgrad') else k)
         agg[fam][0] += float(r['Counter_Value'])
         agg[fam][1] += 1
