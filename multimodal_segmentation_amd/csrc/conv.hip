@@ -395,13 +395,19 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
         }
     };
 
-    f32x16 acc[TM][TN];
+    // A 32x32x2 MFMA takes 16 passes; back-to-back MFMAs into the SAME accumulator stall on the previous result.  Waves
+    // with fewer than 4 output tiles therefore keep NACC accumulator sets and rotate over them along K (summed once at the
+    // end), so that every wave always has >= 4 independent MFMA chains in flight.
+    constexpr int NACC = (TM * TN >= 4) ? 1 : 4 / (TM * TN);
+    f32x16 acc[NACC][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int s = 0; s < NACC; ++s)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][i][j][r] = 0.f;
 
     const int nkt = p.K / BK;
     load_tile();
@@ -429,11 +435,17 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+                        acc[t % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[t % NACC][i][j], 0, 0, 0);
         }
         if (kt + 1 < nkt) store_tile(cur ^ 1);  // the other buffer was last read one iteration ago (barrier below)
         __syncthreads();
     }
+#pragma unroll
+    for (int s = 1; s < NACC; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[0][i][j] += acc[s][i][j];
 
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -451,7 +463,7 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
                     const int oh = orr / p.Wo, ow = orr - oh * p.Wo;
                     m = (ob * p.oH + oh * p.osh + p.ooh) * p.oW + ow * p.osw + p.oow;
                 }
-                const float v = act_apply(acc[i][j][r] + bv, p.act, p.alpha);
+                const float v = act_apply(acc[0][i][j][r] + bv, p.act, p.alpha);
                 if (p.y2 == nullptr) p.y[(size_t)m * p.Cout + n] = v;
                 else if (n < p.nsplit1) p.y[(size_t)m * p.nsplit1 + n] = v;
                 else p.y2[(size_t)m * (p.Cout - p.nsplit1) + (n - p.nsplit1)] = v;

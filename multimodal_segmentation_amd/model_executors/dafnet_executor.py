@@ -360,7 +360,7 @@ class DAFNetExecutor(Executor):
     def _sample(self, pool, batch_size):
         """utils.data_utils.sample: np.random.choice(len, size, replace=False), gathered on the device"""
         idx = data_utils.sample_indices(pool.shape[0], batch_size)
-        return pool.index_select(0, torch.as_tensor(idx, dtype=torch.long, device=pool.device))
+        return pool.index_select(0, nn.host_to_device(idx, pool.device, np.int64))
 
     def train_batch_mask_discriminator(self, epoch_loss):
         """dafnet_executor.py:511-545"""
@@ -402,7 +402,7 @@ class _Indexable(object):
 
     def __getitem__(self, idx):
         if isinstance(self.a, torch.Tensor):
-            return self.a.index_select(0, torch.as_tensor(idx, dtype=torch.long, device=self.a.device))
+            return self.a.index_select(0, nn.host_to_device(idx, self.a.device, np.int64))
         return self.a[idx]
 
 

@@ -19,7 +19,7 @@ the global RNG right after `next(gen)`), keeps the arrays resident in HBM and pr
 import numpy as np
 import torch
 
-from .. import ops
+from .. import nn, ops
 
 
 def rotation_matrices(thetas, H, W):
@@ -74,8 +74,8 @@ class RotationFlow(object):
 
     def __next__(self):
         rows, thetas = self.stream.next()
-        rows_d = torch.as_tensor(rows.astype(np.int32)).to(self.device)
-        mat_d = torch.as_tensor(rotation_matrices(thetas, self.H, self.W)).to(self.device)
+        rows_d = nn.host_to_device(rows, self.device, np.int32)
+        mat_d = nn.host_to_device(rotation_matrices(thetas, self.H, self.W), self.device, np.float32)
         out = tuple(ops.affine_gather(a, rows_d, mat_d, self.order) for a in self.arrays)
         return out if len(out) > 1 else out[0]
 
