@@ -242,7 +242,11 @@ def main():
     _progress('building executor + data')
     ex = DAFNetExecutor(conf, model)
     ex.keep_losses_on_device = True
-    ex.init_train_data(device_resident=True, slices_per_volume=max(2, (2 * args.batch + 13) // 14))
+    # synthetic volumes: the smallest number of slices per volume for which every generator (14 labelled volumes; 2 x 14 for
+    # the real masks) yields FULL batches only -- a short last batch of a pass would make some discriminator steps cheaper
+    # than the workload's
+    spv = next(s for s in range(2, 2 + 4 * args.batch) if (14 * s) % args.batch == 0)
+    ex.init_train_data(device_resident=True, slices_per_volume=spv)
 
     timer = ConvTimer(1 if args.conv_breakdown else args.conv_timer_stride)
     if not args.no_conv_timer:
