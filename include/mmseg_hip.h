@@ -44,6 +44,11 @@ extern "C" {
 int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, float* y, float* y2,
                      int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                      int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, void* stream);
+/* y = act(conv(x) * oscale[c] + bias[c]): convolution + inference-mode BatchNormalization (+ReLU) in one launch (`predict` of the
+ * conv blocks of models/unet.py:94-101 and model_components/segmentor.py:16-22); oscale / bias from mmseg_bn_infer_fold */
+int mmseg_conv2d_fwd_scaled(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, const float* oscale,
+                            float* y, int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                            int pad_h, int pad_w, int ups, int act, float alpha, void* stream);
 /* fast path (Cin % 32 == 0, not transposed): K tiles lie inside one tap, gather by buffer loads, weights read from
  * `wt` = the kernel re-laid out as [Cout][K] by mmseg_conv2d_wprep (mode 0 forward, mode 1 data gradient incl. the
  * spatial flip); pass wt = NULL to force the generic kernel. */
@@ -120,6 +125,10 @@ int mmseg_bn_stats(const float* x, const float* gamma, const float* beta, float*
                    float* mov_mean, float* mov_var, float* ws, long M, int C, float eps, float momentum, void* stream);
 int mmseg_bn_infer_prep(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float* scale, float* shift,
                         int C, float eps, void* stream);
+/* the same folded behind a convolution with bias conv_bias (may be NULL): scale = gamma / sqrt(var + eps),
+ * shift = beta - mean * scale + conv_bias * scale  ->  bn(conv + conv_bias) = conv * scale + shift */
+int mmseg_bn_infer_fold(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, const float* conv_bias,
+                        float* scale, float* shift, int C, float eps, void* stream);
 int mmseg_bn_apply(const float* x, const float* scale, const float* shift, float* y, long M, int C, int relu, void* stream);
 int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean, const float* invstd,
                  float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, void* stream);

@@ -28,6 +28,7 @@ struct ConvParams {
     const float* w;
     const float* wt;    // fast path only: the same kernel as [Cout][K] (K-contiguous rows), see mmseg_conv2d_wprep
     const float* bias;
+    const float* oscale;   // optional per-output-channel scale applied BEFORE the bias (inference BatchNorm folded in)
     float* y;
     float* y2;      // second output for channel-split epilogue (dgrad of a concat conv) or nullptr
     int B, H, W;    // logical input spatial size (after optional up-sampling)
@@ -246,13 +247,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvParams p) {
         const int n = n0 + wn * (BN / WN) + j * 32 + li;
         if (n >= p.Cout) continue;
         const float bv = p.bias ? p.bias[n] : 0.f;
+        const float sv = p.oscale ? p.oscale[n] : 1.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= p.M) continue;
-                const float v = act_apply(acc[i][j][r] + bv, p.act, p.alpha);
+                const float v = act_apply(acc[i][j][r] * sv + bv, p.act, p.alpha);
                 if (p.y2 == nullptr) p.y[(size_t)m * p.Cout + n] = v;
                 else if (n < p.nsplit1) p.y[(size_t)m * p.nsplit1 + n] = v;
                 else p.y2[(size_t)m * (p.Cout - p.nsplit1) + (n - p.nsplit1)] = v;
@@ -452,6 +454,7 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
         const int n = n0 + wn * (BN / WN) + j * 32 + li;
         if (n >= p.Cout) continue;
         const float bv = p.bias ? p.bias[n] : 0.f;
+        const float sv = p.oscale ? p.oscale[n] : 1.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -463,7 +466,7 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
                     const int oh = orr / p.Wo, ow = orr - oh * p.Wo;
                     m = (ob * p.oH + oh * p.osh + p.ooh) * p.oW + ow * p.osw + p.oow;
                 }
-                const float v = act_apply(acc[0][i][j][r] + bv, p.act, p.alpha);
+                const float v = act_apply(acc[0][i][j][r] * sv + bv, p.act, p.alpha);
                 if (p.y2 == nullptr) p.y[(size_t)m * p.Cout + n] = v;
                 else if (n < p.nsplit1) p.y[(size_t)m * p.nsplit1 + n] = v;
                 else p.y2[(size_t)m * (p.Cout - p.nsplit1) + (n - p.nsplit1)] = v;
@@ -573,7 +576,7 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (p.M <= 0 || p.Cout <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
     if (p.C1 == 8 && p.C2 == 0 && p.Cout == 8 && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.transposed && !p.ups &&
         p.Ho == p.H && p.Wo == p.W && p.pad_h == 1 && p.pad_w == 1 && p.y2 == nullptr && p.w != nullptr && p.osh == 1 &&
-        aligned16(p.x1) && aligned16(p.y)) {
+        p.oscale == nullptr && aligned16(p.x1) && aligned16(p.y)) {
         hipLaunchKernelGGL((conv_direct_kernel<8, 8, 3>), dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st,
                            p.x1, p.w, p.bias, p.y, p.B, p.H, p.W, 1, p.act, p.alpha);
         return MMSEG_CHECK_LAUNCH();
@@ -1139,13 +1142,14 @@ __global__ void wprep_parity_kernel(const float* __restrict__ w, float* __restri
 extern "C" {
 
 // Geometry arrays are plain ints so the ABI stays free of C++ types (see include/mmseg_hip.h).
-static int conv2d_fwd_impl(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, float* y, float* y2,
+static int conv2d_fwd_impl(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, const float* oscale,
+                           float* y, float* y2,
                            int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                            int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1,
                            int oH, int oW, int osh, int osw, int ooh, int oow, void* stream) {
     ConvParams p;
     p.oH = oH; p.oW = oW; p.osh = osh; p.osw = osw; p.ooh = ooh; p.oow = oow;
-    p.x1 = x1; p.x2 = x2; p.w = w; p.wt = wt; p.bias = bias; p.y = y; p.y2 = y2;
+    p.x1 = x1; p.x2 = x2; p.w = w; p.wt = wt; p.bias = bias; p.oscale = oscale; p.y = y; p.y2 = y2;
     p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
     p.H1 = ups ? H / 2 : H; p.W1 = ups ? W / 2 : W;
     p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
@@ -1160,8 +1164,17 @@ static int conv2d_fwd_impl(const float* x1, const float* x2, const float* w, con
 int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, float* y, float* y2,
                      int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                      int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, void* stream) {
-    return conv2d_fwd_impl(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad_h, pad_w, ups,
+    return conv2d_fwd_impl(x1, x2, w, wt, bias, nullptr, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad_h, pad_w, ups,
                            transposed, act, alpha, nsplit1, Ho, Wo, 1, 1, 0, 0, stream);
+}
+// y = act(conv(x) * oscale[c] + bias[c]): a convolution followed by an inference-mode BatchNormalization (+ReLU) in one
+// launch -- `predict` of the UNet / segmentor conv blocks (models/unet.py:94-101 with moving statistics); oscale / bias
+// from mmseg_bn_infer_fold.  Same operands as mmseg_conv2d_fwd otherwise (stride-1 or strided, fused up-sampling / concat).
+int mmseg_conv2d_fwd_scaled(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, const float* oscale,
+                            float* y, int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                            int pad_h, int pad_w, int ups, int act, float alpha, void* stream) {
+    return conv2d_fwd_impl(x1, x2, w, wt, bias, oscale, y, nullptr, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad_h, pad_w, ups,
+                           0, act, alpha, 0, Ho, Wo, 1, 1, 0, 0, stream);
 }
 // One parity class (ph, pw) of the data gradient of a stride-s convolution (s = 2), exact taps only:
 //   dx[b, s*i + ph, s*j + pw, :] = sum_{a,b2} dy[b, i - a, j - b2, :] . W[ph + s*a, pw + s*b2, :, :]^T
@@ -1171,7 +1184,7 @@ int mmseg_conv2d_dgrad_parity(const float* dy, const float* wt, float* dx, int B
                               int TH, int TW, int stride, int ph, int pw, void* stream) {
     const int Hs = (H - ph + stride - 1) / stride, Ws = (W - pw + stride - 1) / stride;
     if (Hs <= 0 || Ws <= 0) return 0;
-    return conv2d_fwd_impl(dy, nullptr, nullptr, wt, nullptr, dx, nullptr, B, Ho, Wo, Cout, 0, Hs, Ws, Cin, TH, TW, 1, TH - 1, TW - 1,
+    return conv2d_fwd_impl(dy, nullptr, nullptr, wt, nullptr, nullptr, dx, nullptr, B, Ho, Wo, Cout, 0, Hs, Ws, Cin, TH, TW, 1, TH - 1, TW - 1,
                            0, 0, 0, 0.f, 0, H, W, stride, stride, ph, pw, stream);
 }
 
@@ -1208,7 +1221,7 @@ int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* d
             if (TH > 0 && TW > 0 && Hs > 0 && Ws > 0) {
                 ConvParams& p = pb.p[n++];
                 p.oH = H; p.oW = W; p.osh = stride; p.osw = stride; p.ooh = ph; p.oow = pw;
-                p.x1 = dy; p.x2 = nullptr; p.w = nullptr; p.wt = wt_all + woff; p.bias = nullptr; p.y = dx; p.y2 = nullptr;
+                p.x1 = dy; p.x2 = nullptr; p.w = nullptr; p.wt = wt_all + woff; p.bias = nullptr; p.oscale = nullptr; p.y = dx; p.y2 = nullptr;
                 p.B = B; p.H = Ho; p.W = Wo; p.C1 = Cout; p.C2 = 0; p.H1 = Ho; p.W1 = Wo;
                 p.Ho = Hs; p.Wo = Ws; p.Cout = Cin; p.KH = TH; p.KW = TW; p.stride = 1;
                 p.pad_h = TH - 1; p.pad_w = TW - 1; p.ups = 0; p.transposed = 0; p.act = 0; p.alpha = 0.f;
@@ -1260,7 +1273,7 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
                        int pad_h, int pad_w, int ups, int accumulate, void* stream) {
     WgradParams q;
     ConvParams& p = q.c;
-    p.x1 = x1; p.x2 = x2; p.w = nullptr; p.wt = nullptr; p.bias = nullptr; p.y = nullptr; p.y2 = nullptr;
+    p.x1 = x1; p.x2 = x2; p.w = nullptr; p.wt = nullptr; p.bias = nullptr; p.oscale = nullptr; p.y = nullptr; p.y2 = nullptr;
     p.B = B; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2;
     p.H1 = ups ? H / 2 : H; p.W1 = ups ? W / 2 : W;
     p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;

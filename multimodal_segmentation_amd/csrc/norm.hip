@@ -153,6 +153,17 @@ __global__ void bn_infer_prep_kernel(const float* __restrict__ gamma, const floa
     scale[c] = sc; shift[c] = beta[c] - mov_mean[c] * sc;
 }
 
+// inference BatchNorm folded behind a convolution with bias b: bn(conv + b) = conv * scale + (shift + b * scale)
+__global__ void bn_infer_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mov_mean,
+                                     const float* __restrict__ mov_var, const float* __restrict__ conv_bias, float* __restrict__ scale,
+                                     float* __restrict__ shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(mov_var[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mov_mean[c] * sc + (conv_bias ? conv_bias[c] * sc : 0.f);
+}
+
 // y = x * scale[c] + shift[c]  (+ReLU)
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                 float* __restrict__ y, long n4, int C4, int relu) {
@@ -343,6 +354,12 @@ int mmseg_bn_stats(const float* x, const float* gamma, const float* beta, float*
 int mmseg_bn_infer_prep(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float* scale, float* shift,
                         int C, float eps, void* stream) {
     hipLaunchKernelGGL(bn_infer_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mov_mean, mov_var, scale, shift, C, eps);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_bn_infer_fold(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, const float* conv_bias,
+                        float* scale, float* shift, int C, float eps, void* stream) {
+    hipLaunchKernelGGL(bn_infer_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mov_mean, mov_var,
+                       conv_bias, scale, shift, C, eps);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_bn_apply(const float* x, const float* scale, const float* shift, float* y, long M, int C, int relu, void* stream) {

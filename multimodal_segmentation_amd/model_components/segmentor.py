@@ -19,8 +19,8 @@ class Segmentor(nn.Model):
         self.output_shape = self.input_shape[:-1] + (conf.num_masks + 1,)
 
     def forward(self, s, training=False):
-        l = nn.bn(self, 'c0_bn', nn.conv(self, 'c0', s, bias_grad=not training), training, relu=True)
-        l = nn.bn(self, 'c1_bn', nn.conv(self, 'c1', l, bias_grad=not training), training, relu=True)
+        l = nn.conv_bn(self, 'c0', 'c0_bn', s, training, relu=True)
+        l = nn.conv_bn(self, 'c1', 'c1_bn', l, training, relu=True)
         self.last_logits = nn.conv(self, 'out', l)
         return ops.softmax(self.last_logits)
 

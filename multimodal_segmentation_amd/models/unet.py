@@ -18,10 +18,8 @@ def declare_conv_block(m, name, cin, f):
 
 def conv_block(m, name, x, training, x2=None):
     """reference models/unet.py:94-101"""
-    l = nn.conv(m, name + 'a', x, x2=x2, bias_grad=not training)
-    l = nn.bn(m, name + 'a_bn', l, training, relu=True)
-    l = nn.conv(m, name + 'b', l, bias_grad=not training)
-    return nn.bn(m, name + 'b_bn', l, training, relu=True)
+    l = nn.conv_bn(m, name + 'a', name + 'a_bn', x, training, relu=True, x2=x2)
+    return nn.conv_bn(m, name + 'b', name + 'b_bn', l, training, relu=True)
 
 
 def declare_unet_down(m, cin, f, downsample=4):
@@ -59,7 +57,7 @@ def unet_bottleneck_upsample(m, l, skips, training, downsample=4):
     l = conv_block(m, 'bott', l, training)
     for i in reversed(range(downsample)):
         n = 'u%d' % i
-        l = nn.conv(m, n, l, upsample=True, bias_grad=not training)   # UpSampling2D(2) + Conv2D, fused
-        l = nn.bn(m, n + '_bn', l, training, relu=False)    # activation='linear' (unet.py:67,72,77,82)
+        # UpSampling2D(2) + Conv2D fused; BatchNorm with activation='linear' (unet.py:67,72,77,82)
+        l = nn.conv_bn(m, n, n + '_bn', l, training, relu=False, upsample=True)
         l = conv_block(m, n + 'c', l, training, x2=skips[i])  # Concatenate([l, skip]) fused into the conv
     return l

@@ -325,6 +325,19 @@ def bn(m, name, x, training, relu=False):
                          ggrad=g.g(), bgrad=b.g(), anchor=anchor(x.device))
 
 
+def conv_bn(m, cname, bname, x, training, relu=False, x2=None, upsample=False):
+    """Conv2D(3x3 'same') -> BatchNormalization [-> ReLU].  Training: the two layers as separate launches (batch statistics
+    need the whole convolution output first).  Inference without a tape (`predict`): one launch, BatchNorm folded into
+    the convolution epilogue."""
+    if training or torch.is_grad_enabled():
+        l = conv(m, cname, x, x2=x2, upsample=upsample, bias_grad=not training)
+        return bn(m, bname, l, training, relu=relu)
+    w, b = m.params[cname + '/kernel'], m.params.get(cname + '/bias')
+    return ops.conv2d_bn_infer(x, w.data, b.data if b is not None else None, m.params[bname + '/gamma'].data,
+                               m.params[bname + '/beta'].data, m.params[bname + '/moving_mean'].data,
+                               m.params[bname + '/moving_variance'].data, relu=relu, x2=x2, upsample=upsample, wkey=id(w))
+
+
 # ---- Keras 2.1.6 Adam over the arenas of a set of models -------------------------------------------------------
 class Adam(object):
     """keras.optimizers.Adam(lr): beta (0.9, 0.999), epsilon 1e-7, bias correction folded into lr_t.  One instance

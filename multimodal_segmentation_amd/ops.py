@@ -236,6 +236,26 @@ class _Conv2d(torch.autograd.Function):
         return (dx1, dx2) + (None,) * 11
 
 
+def conv2d_bn_infer(x, w, cbias, gamma, beta, mov_mean, mov_var, relu=False, x2=None, upsample=False, wkey=None):
+    """`predict` of Conv2D -> BatchNormalization [-> ReLU] as ONE launch: the moving statistics are folded into a
+    per-channel scale and bias of the convolution epilogue (no tape: inference only)."""
+    x1 = _c(x)
+    x2 = _c(x2) if x2 is not None else None
+    B, H1, W1, C1 = x1.shape
+    H, W = (2 * H1, 2 * W1) if upsample else (H1, W1)
+    C2 = x2.shape[3] if x2 is not None else 0
+    KH, KW, Cin, Cout = w.shape
+    assert Cin == C1 + C2
+    Ho, Wo, ph, pw = _conv_geometry(H, W, KH, KW, 1, 'same')
+    ss = _new((2, Cout), x1)
+    N.call('mmseg_bn_infer_fold', gamma, beta, mov_mean, mov_var, cbias, ss[0], ss[1], Cout, BN_EPS)
+    y = _new((B, Ho, Wo, Cout), x1)
+    wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
+    N.call('mmseg_conv2d_fwd_scaled', x1, x2, w, wt, ss[1], ss[0], y, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, 1, ph, pw,
+           int(bool(upsample)), ACT['relu' if relu else None], 0.0)
+    return y
+
+
 def conv2d(x, w, bias=None, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False,
            wgrad=None, bgrad=None, anchor=None, wkey=None):
     """keras Conv2D on NHWC (+ fused nearest x2 up-sampling of x, + fused channel concat with x2, + fused

@@ -82,6 +82,21 @@ def conv2d_fwd(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW
     return 0
 
 
+def conv2d_fwd_scaled(x1, x2, w, wt, bias, oscale, y, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, act, alpha):
+    tmp = torch.empty_like(y)
+    conv2d_fwd(x1, x2, w, wt, None, tmp, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, 0, 0, 0.0, 0)
+    v = tmp.reshape(-1, Cout) * oscale.reshape(1, Cout) + (bias.reshape(1, Cout) if bias is not None else 0.0)
+    y.copy_(_act(v, act, alpha).reshape(y.shape))
+    return 0
+
+
+def bn_infer_fold(gamma, beta, mm, mv, conv_bias, scale, shift, C, eps):
+    sc = gamma / torch.sqrt(mv + eps)
+    scale.copy_(sc)
+    shift.copy_(beta - mm * sc + (conv_bias * sc if conv_bias is not None else 0.0))
+    return 0
+
+
 def conv2d_wgrad_workspace(B, Ho, Wo, Cin, Cout, KH, KW):
     return 0
 

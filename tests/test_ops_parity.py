@@ -357,3 +357,27 @@ def test_row_dot(device):
     ls = [rnd(4, 1, seed=10), rnd(4, seed=11), rnd(4, 1, seed=12)]
     check(lambda w_, a, b, c: P.row_dot(w_, [a, b, c]),
           lambda w_, a, b, c: w_[:, 0:1] * a + w_[:, 1:2] * b.reshape(-1, 1) + w_[:, 2:3] * c, [w] + ls, device)
+
+
+@pytest.mark.parametrize('C1,C2,Cout,ups,relu', [(64, 0, 64, False, True), (1, 0, 64, False, True), (128, 0, 64, True, False),
+                                                  (64, 64, 64, False, True), (8, 0, 64, False, True)])
+def test_conv_bn_infer_fused(C1, C2, Cout, ups, relu, device):
+    """`predict` of Conv2D -> BatchNormalization [-> ReLU] in one launch == the oracle's two layers with moving statistics"""
+    B, H, W = 2, 16, 16
+    x1 = rnd(B, H // 2 if ups else H, W // 2 if ups else W, C1, seed=1)
+    x2 = rnd(B, H, W, C2, seed=2) if C2 else None
+    w = rnd(3, 3, C1 + C2, Cout, seed=3, scale=(2.0 / (9 * (C1 + C2))) ** 0.5)
+    cb, gamma, beta = rnd(Cout, seed=4, scale=0.1), torch.rand(Cout) + 0.5, rnd(Cout, seed=5, scale=0.2)
+    mm, mv = rnd(Cout, seed=6, scale=0.3), torch.rand(Cout) + 0.3
+    d = lambda t: t.to(device) if t is not None else None
+    with torch.no_grad():
+        y = P.conv2d_bn_infer(d(x1), d(w), d(cb), d(gamma), d(beta), d(mm), d(mv), relu=relu, x2=d(x2), upsample=ups)
+    D = lambda t: t.double()
+    xin = O.upsample2(D(x1)) if ups else D(x1)
+    if x2 is not None:
+        xin = torch.cat([xin, D(x2)], -1)
+    Pd = {'bn/gamma': D(gamma), 'bn/beta': D(beta), 'bn/moving_mean': D(mm), 'bn/moving_variance': D(mv)}
+    ref = O.batchnorm(O.conv2d(xin, D(w), D(cb)), Pd, 'bn', False)
+    if relu:
+        ref = torch.relu(ref)
+    _close(y, ref, 'conv+bn(infer)')
