@@ -52,8 +52,8 @@ class ConvTimer(object):
         timer = self
 
         def call(name, *args):
-            if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_wgrad', 'mmseg_conv2d_dgrad_parity',
-                                          'mmseg_conv2d_dgrad_parity_all'):
+            if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_fwd_scaled', 'mmseg_conv2d_wgrad',
+                                          'mmseg_conv2d_dgrad_parity', 'mmseg_conv2d_dgrad_parity_all'):
                 if name == 'mmseg_conv2d_dgrad_parity_all':
                     (B, Ho, Wo, Cout, H, W, Cin, KH, KW, stride) = args[3:13]
                     # the parity classes together touch every (output pixel, tap) pair of the strided convolution once
@@ -68,6 +68,13 @@ class ConvTimer(object):
                     nbytes = 4.0 * (B * Ho * Wo * Cout + TH * TW * Cin * Cout + B * hs * ws * Cin)
                     kind = 'conv_fwd_kernel'
                     shape = ('dgrad_parity', B, Ho, Wo, Cout, Cin, TH, TW, stride)
+                elif name == 'mmseg_conv2d_fwd_scaled':          # convolution + folded inference BatchNorm (+ReLU)
+                    (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[7:17]
+                    ups = args[20]
+                    flops = 2.0 * B * Ho * Wo * Cout * KH * KW * (C1 + C2)
+                    nbytes = 4.0 * (B * (H >> ups) * (W >> ups) * C1 + B * H * W * C2 + KH * KW * (C1 + C2) * Cout + B * Ho * Wo * Cout)
+                    kind = 'conv_fwd_kernel'
+                    shape = ('fwd+bn', B, H, W, C1, C2, Cout, KH, KW, 'ups' if ups else '')
                 elif name == 'mmseg_conv2d_fwd':
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[7:17]
                     transposed = args[21]
