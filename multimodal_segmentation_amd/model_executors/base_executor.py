@@ -52,18 +52,6 @@ class Executor(object):
         return RotationFlow(arrays, self.conf.batch_size, self.conf.seed, self.device, rotation_range=p['rotation_range'],
                             order=self.conf.get('augment_interpolation_order', 1))
 
-    @staticmethod
-    def batch_iterator(arrays, batch_size, rng):
-        """Infinite iterator over aligned arrays: reshuffles every pass, yields tuples of batches (the last batch of
-        a pass may be smaller, like keras' NumpyArrayIterator)."""
-        n = arrays[0].shape[0]
-        while True:
-            order = rng.permutation(n)
-            for i in range(0, n, batch_size):
-                idx = order[i:i + batch_size]
-                out = tuple(a[idx] for a in arrays)
-                yield out if len(out) > 1 else out[0]
-
     def validate(self, epoch_loss):
         pass
 

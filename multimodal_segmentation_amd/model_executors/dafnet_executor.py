@@ -393,19 +393,6 @@ class DAFNetExecutor(Executor):
         return h.history._dev[key] if self.keep_losses_on_device else h.history[key][0]
 
 
-class _Indexable(object):
-    """array or device tensor with numpy-index-array batching"""
-
-    def __init__(self, a):
-        self.a = a
-        self.shape = a.shape
-
-    def __getitem__(self, idx):
-        if isinstance(self.a, torch.Tensor):
-            return self.a.index_select(0, nn.host_to_device(idx, self.a.device, np.int64))
-        return self.a[idx]
-
-
 def _dev(x, device):
     return nn.to_device(x, device)
 

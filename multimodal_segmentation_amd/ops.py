@@ -78,23 +78,6 @@ def _wprep(w, KH, KW, Cin, Cout, mode, wkey=None):
     return out
 
 
-def _wprep_parity(w, KH, KW, Cin, Cout, stride, ph, pw, ntaps, wkey=None):
-    """Sub-kernel of one parity class of a strided convolution's data gradient (fast layout); cached like _wprep."""
-    n = ntaps * Cin * Cout
-    if wkey is None:
-        out = _ws('wprep_parity', n, w.device)[:n]
-        N.call('mmseg_conv2d_wprep_parity', w, out, KH, KW, Cin, Cout, stride, ph, pw)
-        return out
-    key = (wkey, w.data_ptr(), 'parity', stride, ph, pw)
-    ent = _wprep_cache.get(key)
-    if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == n:
-        return ent[1]
-    out = ent[1] if (ent is not None and ent[1].numel() == n) else torch.empty(n, dtype=torch.float32, device=w.device)
-    N.call('mmseg_conv2d_wprep_parity', w, out, KH, KW, Cin, Cout, stride, ph, pw)
-    _wprep_cache[key] = (_weight_version[0], out)
-    return out
-
-
 def _wprep_parity_all(w, KH, KW, Cin, Cout, stride, taps, wkey=None):
     """The sub-kernels of all stride x stride parity classes back to back in (ph, pw) raster order (the operand of
     mmseg_conv2d_dgrad_parity_all); cached per weight version like _wprep."""

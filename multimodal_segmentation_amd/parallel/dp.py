@@ -112,20 +112,6 @@ def finish(tracker):
     tracker.finish()
 
 
-def allreduce_gradients(models):
-    """Average the gradient arenas of `models` over the ranks (in place)."""
-    if not enabled():
-        return
-    ws = float(dist.get_world_size())
-    works = []
-    for m in models:
-        works.append((m, dist.all_reduce(m.grad_arena, op=dist.ReduceOp.SUM, async_op=True)))
-    from .. import ops
-    for m, w in works:
-        w.wait()
-        ops.axpby(m.grad_arena, m.grad_arena, 1.0 / ws, 0.0, out=m.grad_arena)
-
-
 def broadcast_models(models, src=0):
     if not enabled():
         return
