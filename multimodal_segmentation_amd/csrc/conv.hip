@@ -301,7 +301,14 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
     const int li = lane & 31, lh = lane >> 5;
     const int ntn = (p.Cout + BN - 1) / BN;
     const int lb = xcd_remap(bid, nblk);
-    const int mt = lb / ntn, n0 = (lb % ntn) * BN;
+    // Consecutive logical ids land on one XCD (one L2).  Let them share the BIGGER operand: for the shallow layers that
+    // is the pixel panel (all N tiles of one pixel tile run back to back); for the deep layers the kernel matrix is
+    // larger than the activations (16x16x1024 -> 1024: 37.7 MB of weights vs 8.4 MB of pixels), so there the pixel tiles
+    // of one N tile run back to back and every weight slice is fetched by one XCD instead of by all eight.
+    const int ntm = nblk / ntn;
+    const bool w_major = (long)p.K * p.Cout > (long)p.M * (p.C1 + p.C2);
+    const int mt = w_major ? lb % ntm : lb / ntn;
+    const int n0 = (w_major ? lb / ntm : lb % ntn) * BN;
     // 2-D pixel tiles (TH x 16) when the output plane divides evenly: the 9 taps of a tile then re-read an L1-sized
     // halo patch instead of 9 disjoint row segments; otherwise BM consecutive pixels in raster order
     constexpr int TH = BM / 16;
