@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-TFLOP_PER_PAIR = {('film', 256): 1.630, ('spade', 256): 2.871}   # BASELINE.md section 4 (conv MACs x 2)
+TFLOP_PER_PAIR = {('film', 256): 1.630, ('spade', 256): 2.871, ('mmsdnet', 256): 1.469, ('mmsdnet', 320): 2.296}   # BASELINE.md section 4 (conv MACs x 2)
 
 
 class ConvTimer(object):
@@ -197,6 +197,8 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--decoder', default='film', choices=['film', 'spade'])
+    ap.add_argument('--model', default='dafnet', choices=['dafnet', 'mmsdnet'],
+                    help="mmsdnet: the MMSDNet iteration (mmsdnet_executor.py:238-331) instead of the headline DAFNet one")
     ap.add_argument('--l_mix', type=float, default=1.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
@@ -226,13 +228,18 @@ def main():
 
     _native.load()
     nn.set_default_device('cuda:%d' % local_rank)
-    cfg = (dafnet_config_chaos if args.decoder == 'film' else dafnet_spade_config_chaos).get()
+    if args.model == 'mmsdnet':
+        from multimodal_segmentation_amd.configuration import mmsdnet_config_chaos
+        cfg = mmsdnet_config_chaos.get()
+    else:
+        cfg = (dafnet_config_chaos if args.decoder == 'film' else dafnet_spade_config_chaos).get()
     H = args.size
     cfg['input_shape'] = (H, H, 1)
     cfg['anatomy_encoder']['input_shape'] = (H, H, 1)
     cfg['anatomy_encoder']['output_shape'] = (H, H, 8)
     cfg['d_mask_params']['input_shape'] = (H, H, cfg['num_masks'])
-    cfg['d_image_params']['input_shape'] = (H, H, 1)
+    if 'd_image_params' in cfg:
+        cfg['d_image_params']['input_shape'] = (H, H, 1)
     cfg['batch_size'] = args.batch
     cfg['l_mix'] = args.l_mix
     cfg['n_pairs'] = 1
@@ -240,11 +247,16 @@ def main():
     conf = EasyDict(cfg)
 
     _progress('building model')
+    if args.model == 'mmsdnet':
+        from multimodal_segmentation_amd.models.mmsdnet import MMSDNet
+        from multimodal_segmentation_amd.model_executors.mmsdnet_executor import MMSDNetExecutor
+        DAFNet, DAFNetExecutor = MMSDNet, MMSDNetExecutor
     model = DAFNet(conf)
     model.build()
     dp.enable(world > 1)
     if world > 1:
-        all_models = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
+        all_models = model._generator_models() + [d for d in (model.D_Mask, getattr(model, 'D_Image1', None),
+                                                             getattr(model, 'D_Image2', None)) if d is not None]
         dp.broadcast_models(all_models)
     _progress('building executor + data')
     ex = DAFNetExecutor(conf, model)
@@ -252,7 +264,10 @@ def main():
     # synthetic volumes: the smallest number of slices per volume for which every generator (14 labelled volumes; 2 x 14 for
     # the real masks) yields FULL batches only -- a short last batch of a pass would make some discriminator steps cheaper
     # than the workload's
-    spv = next(s for s in range(2, 2 + 4 * args.batch) if (14 * s) % args.batch == 0)
+    n_lab = int(round(args.l_mix * 14))
+    n_ul = 14 - n_lab if args.l_mix < 1 else 0
+    sizes = [n for n in (n_lab, n_ul, 2 * n_lab + n_ul, 14) if n > 0]      # labelled, unlabelled, real masks, all images
+    spv = next(s for s in range(2, 2 + 8 * args.batch) if all((n * s) % args.batch == 0 for n in sizes))
     ex.init_train_data(device_resident=True, slices_per_volume=spv)
 
     timer = ConvTimer(1 if args.conv_breakdown else args.conv_timer_stride)
@@ -290,7 +305,8 @@ def main():
     pairs = world * args.batch * args.steps * passes
     value = pairs / dt
     line = {
-        'metric': '2D slices/sec DAFNet train step, %dx%dx2-modality bs=%d/GPU' % (H, H, args.batch),
+        'metric': '2D slices/sec %s train step, %dx%dx2-modality bs=%d/GPU' % ('DAFNet' if args.model == 'dafnet' else 'MMSDNet',
+                                                                                H, H, args.batch),
         'value': value, 'unit': 'paired slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
@@ -299,7 +315,11 @@ def main():
                                % (args.decoder, '' if args.decoder == 'film' else '_spade', H, H, args.batch, args.l_mix),
                    'global_batch': world * args.batch, 'parallelism': 'dp%d' % world},
     }
-    key = (args.decoder, H)
+    if args.model == 'mmsdnet':
+        line['config']['workload'] = ('MMSDNet (mmsdnet_config_chaos) %dx%d 2-modality training iteration: generator fit + '
+                                      'Z-regressor fit + mask-D fit incl. the fake pool, bs=%d/GPU, fp32, l_mix=%g'
+                                      % (H, H, args.batch, args.l_mix))
+    key = (args.decoder if args.model == 'dafnet' else 'mmsdnet', H)
     if key in TFLOP_PER_PAIR:
         line['conv_tflops_whole_step'] = TFLOP_PER_PAIR[key] * value / world
         line['conv_roofline_frac_whole_step'] = TFLOP_PER_PAIR[key] * value / world / FP32_MFMA_PEAK_TFLOPS
@@ -331,7 +351,7 @@ def main():
                                       'launches': timer.counts.get('conv_wgrad_kernel', w['launches']), 'timed_launches': w['launches'],
                                       'avg_launch_ms': w['ms'] / w['launches'],
                                       'gpu_ms_per_step': w['ms'] / w['launches'] * timer.counts.get('conv_wgrad_kernel', w['launches']) / args.steps}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == 'dafnet':
             _progress('cpu baseline (oracle, bounded sample)')
             line['cpu_baseline'] = cpu_baseline(H, args.decoder, args.batch)
         print(json.dumps(line))
