@@ -60,8 +60,11 @@ def _cmp(a, b, name, tol=TOL):
     return err
 
 
-@pytest.mark.parametrize('decoder,H,supervised', [('film', 64, True), ('film', 64, False), ('spade', 64, True)])
+@pytest.mark.parametrize('decoder,H,supervised', [('film', 64, True), ('film', 64, False), ('spade', 64, True),
+                                                  ('film', 192, True)])
 def test_generator_step(decoder, H, supervised, device):
+    if H > 64 and device == 'cpu':
+        pytest.skip('the CHAOS-sized case (192x192, the reference configuration default) runs on the GPU only')
     B = 2
     conf, model = _build(decoder, H, device)
     orc = _oracle(model, conf)
@@ -106,8 +109,13 @@ def test_generator_step(decoder, H, supervised, device):
               'adv_y1', 'adv_y2', 'adv_y1_s2_def', 'adv_y2_s1_def', 'kl1', 'kl2', 'z1_rec', 'z2_rec']
     for n, po in zip(names, trainer.last_outputs):
         _cmp(po.cpu().numpy(), oo[n].numpy(), 'output ' + n)
-        if n.startswith('m'):   # arg-max label maps bit-exact
-            assert (po.cpu().numpy().argmax(-1) == oo[n].numpy().argmax(-1)).all(), 'label map ' + n
+        if n.startswith('m'):   # arg-max label maps bit-exact -- wherever the oracle's decision is not a numerical tie
+            ref = oo[n].numpy()
+            top2 = np.sort(ref, axis=-1)[..., -2:]
+            decided = (top2[..., 1] - top2[..., 0]) > 1e-4          # 100x the fp32 error of the softmax outputs
+            same = po.cpu().numpy().argmax(-1) == ref.argmax(-1)
+            assert same[decided].all(), 'label map %s differs on %d decided pixels' % (n, int((~same & decided).sum()))
+            assert decided.mean() > 0.98, 'label map %s: only %.1f%% of the pixels are decided' % (n, 100 * decided.mean())
     # every loss term (keras names, last-wins) and the total
     for k, v in ho.items():
         rel = max(1.0, abs(v))
