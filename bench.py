@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); never the 2:1-sparsity figure
 TFLOP_PER_PAIR = {('film', 256): 1.630, ('spade', 256): 2.871, ('mmsdnet', 256): 1.469, ('mmsdnet', 320): 2.296}   # BASELINE.md section 4 (conv MACs x 2)
 
 
@@ -200,6 +201,8 @@ def main():
     ap.add_argument('--model', default='dafnet', choices=['dafnet', 'mmsdnet'],
                     help="mmsdnet: the MMSDNet iteration (mmsdnet_executor.py:238-331) instead of the headline DAFNet one")
     ap.add_argument('--l_mix', type=float, default=1.0)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='bf16: bf16 MFMA operands (fp32 accumulation, fp32 tensors in HBM, fp32 weight gradients) -- configs #3/#5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
     ap.add_argument('--conv-breakdown', action='store_true', help='per-shape convolution table on stderr')
@@ -243,6 +246,7 @@ def main():
     cfg['batch_size'] = args.batch
     cfg['l_mix'] = args.l_mix
     cfg['n_pairs'] = 1
+    cfg['compute_dtype'] = 'bf16' if args.dtype == 'bf16' else 'fp32'
     cfg['folder'] = '/tmp/mmseg_bench'
     conf = EasyDict(cfg)
 
@@ -309,7 +313,7 @@ def main():
                                                                                 H, H, args.batch),
         'value': value, 'unit': 'paired slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'DAFNet-%s (dafnet%s_config_chaos) %dx%d 2-modality training iteration: generator fit + '
                                '2 mask-D fits + 2 image-D fits incl. fake pools, bs=%d/GPU, fp32, l_mix=%g'
                                % (args.decoder, '' if args.decoder == 'film' else '_spade', H, H, args.batch, args.l_mix),
@@ -332,8 +336,10 @@ def main():
         k = summ.get('conv_fwd_kernel')
         if k:
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
-            line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (implicit-GEMM fp32 MFMA; forward + data-gradient launches)',
-                                'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
+            line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (implicit-GEMM %s MFMA; forward + data-gradient launches)'
+                                                           % ('bf16 (fp32 tensors in HBM, fp32 accumulation)' if args.dtype == 'bf16' else 'fp32'),
+                                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                                 'traffic': traffic.get('conv_fwd', {}).get('hbm_bytes_per_launch'),
                                 'algorithmic_bytes_per_launch': k['bytes'] / k['launches'],
                                 'flops_per_launch': k['flops'] / k['launches'],

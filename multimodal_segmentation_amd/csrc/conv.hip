@@ -48,6 +48,8 @@ struct ConvParams {
 };
 
 #define BK 32
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define AS_LD (BK + 4)
 
 __device__ __forceinline__ f32x4 gather_tap4(const ConvParams& p, int b, int hb, int wb, int kh, int kw, int c) {
@@ -280,7 +282,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BF16 = false>
 __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bid, const int nblk) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -289,7 +291,11 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
     // LDS tiles: 32 floats per row, NO padding; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7, which makes
     // both the ds_write_b128 (8 lanes = 8 chunks of one row) and the ds_read_b128 (16-lane groups over distinct rows)
     // conflict-free and lets 3 blocks of the 128x64 tile share a CU's 160 KB
-    constexpr int LD = BK;
+    // BF16 variant (mmseg_set_conv_precision(1)): the fp32 operands are rounded to bf16 (RNE) on their way into LDS, the tiles
+    // are rows of 32 bf16 = 64 bytes (4 chunks of 16 bytes, chunk index XOR-swizzled with (row >> 1) & 3: conflict-free for
+    // the 8-byte stores and the 16-byte operand reads alike), products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+    // LD counts 4-byte words per row.
+    constexpr int LD = BF16 ? BK / 2 : BK;
     constexpr int A_SZ = BM * LD, B_SZ = BN * LD;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
@@ -394,13 +400,29 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
     auto store_tile = [&](int buf) {
         float* A = As + buf * A_SZ;
         float* Bt = Bs + buf * B_SZ;
+        if constexpr (BF16) {
+            // this thread's 4 consecutive k = half of the 16-byte chunk kc >> 1
 #pragma unroll
-        for (int j = 0; j < A_F4; ++j)
-            *reinterpret_cast<f32x4*>(&A[(ar0 + j * A_RPP) * LD + 4 * (kc ^ (((ar0 + j * A_RPP) >> 1) & 7))]) = ra[j];
+            for (int j = 0; j < A_F4; ++j) {
+                const int row = ar0 + j * A_RPP;
+                bf16x4 v = {(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
+                *reinterpret_cast<bf16x4*>(&A[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)]) = v;
+            }
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) {
-            const int row = ar0 + j * A_RPP;
-            if (row < BN) *reinterpret_cast<f32x4*>(&Bt[row * LD + 4 * (kc ^ ((row >> 1) & 7))]) = rb[j];
+            for (int j = 0; j < B_F4; ++j) {
+                const int row = ar0 + j * A_RPP;
+                bf16x4 v = {(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
+                if (row < BN) *reinterpret_cast<bf16x4*>(&Bt[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)]) = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_F4; ++j)
+                *reinterpret_cast<f32x4*>(&A[(ar0 + j * A_RPP) * LD + 4 * (kc ^ (((ar0 + j * A_RPP) >> 1) & 7))]) = ra[j];
+#pragma unroll
+            for (int j = 0; j < B_F4; ++j) {
+                const int row = ar0 + j * A_RPP;
+                if (row < BN) *reinterpret_cast<f32x4*>(&Bt[row * LD + 4 * (kc ^ ((row >> 1) & 7))]) = rb[j];
+            }
         }
     };
 
@@ -429,22 +451,40 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
         if (kt + 1 < nkt) load_tile();          // buffer loads in flight under the MFMAs
         const float* A = As + cur * A_SZ;
         const float* Bt = Bs + cur * B_SZ;
+        if constexpr (BF16) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 a[TM], b[TN];
+            for (int q = 0; q < 2; ++q) {            // two k-steps of 16; lane half lh supplies k = 16 q + 8 lh + [0, 8)
+                bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ (((a_row + i * 32) >> 1) & 7))]);
+                for (int i = 0; i < TM; ++i)
+                    a[i] = *reinterpret_cast<const bf16x8*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ (((a_row + i * 32) >> 1) & 3))]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ (((b_col + j * 32) >> 1) & 7))]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int j = 0; j < TN; ++j)
+                    b[j] = *reinterpret_cast<const bf16x8*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ (((b_col + j * 32) >> 1) & 3))]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[t % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[t % NACC][i][j], 0, 0, 0);
+                        acc[q % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[q % NACC][i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 a[TM], b[TN];
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i] = *reinterpret_cast<const f32x4*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ (((a_row + i * 32) >> 1) & 7))]);
+    #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j] = *reinterpret_cast<const f32x4*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ (((b_col + j * 32) >> 1) & 7))]);
+    #pragma unroll
+                for (int t = 0; t < 4; ++t)
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[t % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[t % NACC][i][j], 0, 0, 0);
+            }
         }
         if (kt + 1 < nkt) store_tile(cur ^ 1);  // the other buffer was last read one iteration ago (barrier below)
         __syncthreads();
@@ -482,19 +522,22 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BF16 = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
-    conv_fast_body<BM, BN, WM, WN>(p, blockIdx.x, gridDim.x);
+    conv_fast_body<BM, BN, WM, WN, BF16>(p, blockIdx.x, gridDim.x);
 }
 // up to 4 independent convolutions of one tile configuration in a single launch (blockIdx.y selects the problem): the
 // parity classes of a strided convolution's data gradient are each too small to fill 256 CUs
 struct ConvBatch { ConvParams p[4]; int nblk[4]; };
-template <int BM, int BN, int WM, int WN>
+// 0: fp32 MFMA (default); 1: the fast-path forward / data-gradient convolutions round their operands to bf16 and use the bf16
+// MFMA with fp32 accumulation (activations, weights and weight gradients stay fp32 in HBM) -- mmseg_set_conv_precision
+static int g_conv_bf16 = 0;
+template <int BM, int BN, int WM, int WN, bool BF16 = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fast_batched_kernel(ConvBatch pb) {
     const int z = blockIdx.y;
     const int nb = pb.nblk[z];
     if ((int)blockIdx.x >= nb) return;
-    conv_fast_body<BM, BN, WM, WN>(pb.p[z], blockIdx.x, nb);
+    conv_fast_body<BM, BN, WM, WN, BF16>(pb.p[z], blockIdx.x, nb);
 }
 template <int BM, int BN, int WM, int WN>
 static int launch_fast_batched(ConvBatch& pb, int n, hipStream_t st) {
@@ -505,14 +548,16 @@ static int launch_fast_batched(ConvBatch& pb, int n, hipStream_t st) {
         if (pb.nblk[z] > mx) mx = pb.nblk[z];
     }
     for (int z = n; z < 4; ++z) pb.nblk[z] = 0;
-    hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
+    if (g_conv_bf16) hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN, true>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
+    else hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
     return MMSEG_CHECK_LAUNCH();
 }
 
 template <int BM, int BN, int WM, int WN>
 static int launch_fast(const ConvParams& p, hipStream_t st) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
+    if (g_conv_bf16) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, true>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
+    else hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
     return MMSEG_CHECK_LAUNCH();
 }
 
@@ -1147,6 +1192,15 @@ __global__ void wprep_parity_kernel(const float* __restrict__ w, float* __restri
 }
 
 extern "C" {
+
+// Process-wide precision of the fast-path forward / data-gradient convolutions: 0 = fp32 MFMA, 1 = bf16 MFMA with fp32
+// accumulation (BASELINE configs #3/#5).  Returns the previous mode.  Not a per-launch argument: the trainers switch it once.
+int mmseg_set_conv_precision(int mode) {
+    const int old = g_conv_bf16;
+    g_conv_bf16 = mode ? 1 : 0;
+    return old;
+}
+int mmseg_get_conv_precision(void) { return g_conv_bf16; }
 
 // Geometry arrays are plain ints so the ABI stays free of C++ types (see include/mmseg_hip.h).
 static int conv2d_fwd_impl(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, const float* oscale,

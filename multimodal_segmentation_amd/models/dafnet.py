@@ -32,6 +32,7 @@ class DAFNet(MMSDNet):
         self.D_Image2_trainer = None
 
     def build(self):
+        self.apply_compute_dtype()
         self.build_mask_discriminator()
         self.build_image_discriminator1()
         self.build_image_discriminator2()

@@ -37,7 +37,14 @@ class MMSDNet(BaseNet):
         self.num_masks = conf.num_masks if hasattr(conf, 'num_masks') else self.loader.num_masks
         global_rng(conf.seed if hasattr(conf, 'seed') else 10)
 
+    def apply_compute_dtype(self):
+        """conf.compute_dtype (build-defined key, default 'fp32'): 'bf16' runs the MFMA products of the fast-path forward /
+        data-gradient convolutions on bf16-rounded operands with fp32 accumulation (BASELINE configs #3 / #5: reduced-
+        precision compute, fp32 master weights, fp32 gradient all-reduce).  Process-wide switch of the kernel library."""
+        ops.set_conv_precision(self.conf.get('compute_dtype', 'fp32'))
+
     def build(self):
+        self.apply_compute_dtype()
         self.build_mask_discriminator()
         self.build_generators()
         self.load_models()

@@ -41,6 +41,14 @@ def _c(t):
 # ------------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------------
+def set_conv_precision(mode):
+    """'fp32' (default) or 'bf16': precision of the MFMA products of the fast-path forward / data-gradient convolutions
+    (operands rounded to bf16, fp32 accumulation; tensors in HBM, weight gradients, normalisation, losses and the optimiser
+    stay fp32).  Returns the previous mode."""
+    old = N.call('mmseg_set_conv_precision', {'fp32': 0, 'bf16': 1}[mode])
+    return 'bf16' if old else 'fp32'
+
+
 def _conv_geometry(H, W, KH, KW, stride, padding):
     if padding == 'same':
         if stride != 1 or KH % 2 == 0 or KW % 2 == 0:

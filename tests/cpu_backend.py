@@ -47,6 +47,19 @@ def conv2d_fast_path(C1, C2, Cout, transposed):
     return 0
 
 
+_precision = [0]
+
+
+def set_conv_precision(mode):
+    old = _precision[0]
+    _precision[0] = int(bool(mode))
+    return old
+
+
+def get_conv_precision():
+    return _precision[0]
+
+
 def conv2d_parity_taps(K, stride, p):
     return (K - p + stride - 1) // stride if p < K else 0
 

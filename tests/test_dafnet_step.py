@@ -206,3 +206,39 @@ def test_executor_schedule(l_mix, passes, device):
     assert len(losses['dis_X1']) == passes and len(losses['dis_X2']) == passes
     for k in ('supervised_Mask', 'adv_M', 'rec_X', 'adv_X1', 'adv_X2', 'KL', 'rec_Z', 'dis_M', 'dis_X1', 'dis_X2'):
         assert all(np.isfinite(float(v)) for v in losses[k]), k
+
+
+@pytest.mark.gpu
+def test_generator_step_bf16_compute_close_to_fp32():
+    """conf.compute_dtype = 'bf16' (BASELINE configs #3 / #5: bf16 MFMA operands, fp32 accumulation / storage / weight
+    gradients): every loss term of a generator step stays within 2e-2 of the fp32 step on the same weights and draws, and
+    the process-wide precision switch is restored by the next fp32 build."""
+    from multimodal_segmentation_amd import ops as P
+    nn.set_default_device('cuda:0')
+    B, H = 2, 64
+    d = Hh.make_step_data(B, H, H)
+    res = {}
+    try:
+        for dt in ('fp32', 'bf16'):
+            conf = Hh.make_conf(dafnet_config_chaos, H, compute_dtype=dt)
+            from multimodal_segmentation_amd.utils import rng as R
+            model = DAFNet(conf)
+            model.build()
+            if dt == 'fp32':
+                ref_w = [m.get_weights() for m in model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]]
+            else:
+                for m, w in zip(model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2], ref_w):
+                    m.set_weights(w)
+            B1 = np.ones((B, 1), np.float32)
+            tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [B1] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [B1] * 4 + \
+                 [np.zeros(B, np.float32)] * 2 + [d['z1'], d['z2']]
+            h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']])
+            res[dt] = {k: h.history[k][0] for k in h.history.keys()}
+        assert P.set_conv_precision('fp32') == 'bf16'            # the bf16 build had switched the library
+    finally:
+        P.set_conv_precision('fp32')
+    for k, v in res['fp32'].items():
+        # Segmentor / D losses go through the Rounding layer: a few flipped anatomy pixels move them a little more
+        tol = 5e-2 if k in ('loss', 'Segmentor_loss', 'D_Mask_loss') else 2e-2
+        assert abs(res['bf16'][k] - v) <= tol * max(1.0, abs(v)), (k, v, res['bf16'][k])
+    assert any(abs(res['bf16'][k] - v) > 1e-6 for k, v in res['fp32'].items())      # and bf16 really ran

@@ -381,3 +381,60 @@ def test_conv_bn_infer_fused(C1, C2, Cout, ups, relu, device):
     if relu:
         ref = torch.relu(ref)
     _close(y, ref, 'conv+bn(infer)')
+
+
+def _bf16(t):
+    return t.float().to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,Cin,C2,Cout,k,stride,padding,ups', [
+    (2, 16, 16, 64, 0, 64, 3, 1, 'same', False), (2, 32, 32, 128, 0, 128, 3, 1, 'same', False),
+    (2, 16, 16, 64, 64, 64, 3, 1, 'same', False), (2, 16, 16, 128, 0, 64, 3, 1, 'same', True),
+    (2, 8, 8, 256, 0, 512, 3, 1, 'same', False), (2, 16, 16, 64, 0, 128, 4, 2, 'valid', False),
+    (3, 24, 24, 64, 0, 8, 1, 1, 'same', False)])
+def test_conv2d_bf16_precision(B, H, W, Cin, C2, Cout, k, stride, padding, ups):
+    """mmseg_set_conv_precision(1): forward and data gradient == the fp64 oracle on bf16-rounded operands (the products are
+    then exact, only the fp32 accumulation differs); the weight gradient stays full fp32."""
+    dev = 'cuda'
+    x1 = rnd(B, H // 2 if ups else H, W // 2 if ups else W, Cin, seed=1)
+    x2 = rnd(B, H, W, C2, seed=2) if C2 else None
+    w = rnd(k, k, Cin + C2, Cout, seed=3, scale=(2.0 / (k * k * (Cin + C2))) ** 0.5)
+    b = rnd(Cout, seed=4, scale=0.1)
+    D = lambda t: t.double()
+    xr1 = D(x1).requires_grad_(True)
+    xr2 = D(x2).requires_grad_(True) if C2 else None
+    wr = D(w).requires_grad_(True)
+    xin = O.upsample2(xr1) if ups else xr1
+    if C2:
+        xin = torch.cat([xin, xr2], -1)
+    # forward on rounded operands (rounding has zero derivative, so the straight-through form keeps the graph)
+    rnd_st = lambda t: t + (_bf16(t.detach()) - t.detach())
+    yr = O.conv2d(rnd_st(xin), rnd_st(wr), D(b), stride=stride, padding=padding)
+    cot = rnd(*yr.shape, seed=5)
+    prev = P.set_conv_precision('bf16')
+    try:
+        xp1 = x1.to(dev).requires_grad_(True)
+        xp2 = x2.to(dev).requires_grad_(True) if C2 else None
+        wp, bp = w.to(dev), b.to(dev)
+        wg, bg = torch.zeros_like(wp), torch.zeros_like(bp)
+        y = P.conv2d(xp1, wp, bp, stride=stride, padding=padding, x2=xp2, upsample=ups, wgrad=wg, bgrad=bg, anchor=_anchor(xp1))
+        y.backward(cot.to(dev))
+    finally:
+        P.set_conv_precision(prev)
+    _close(y, yr, 'bf16 forward')
+    # data gradient: the kernel rounds the incoming gradient and the weights -- on the fast path (Cout % 32 == 0); the
+    # generic kernel that serves the other shapes is fp32 only
+    r_ = _bf16 if Cout % 32 == 0 else (lambda t: t.double())
+    gx = torch.autograd.grad(O.conv2d(xin, r_(wr.detach()), None, stride=stride, padding=padding), [xr1] + ([xr2] if C2 else []),
+                             r_(cot))
+    _close(xp1.grad, gx[0], 'bf16 dgrad x1', 4e-4)
+    if C2:
+        _close(xp2.grad, gx[1], 'bf16 dgrad x2', 4e-4)
+    # weight gradient: fp32 path, unrounded operands
+    gw = torch.autograd.grad(O.conv2d(xin.detach(), wr, None, stride=stride, padding=padding), wr, D(cot))[0]
+    _close(wg, gw, 'wgrad (fp32)', 4e-4)
+    # and the rounding is really happening: the result differs from the unrounded oracle by more than fp32 noise
+    y32 = O.conv2d(xin.detach(), D(w), D(b), stride=stride, padding=padding)
+    if Cin >= 32 and Cout % 4 == 0:
+        assert (y.detach().cpu().double() - y32).abs().max() > 1e-4 * y32.abs().max()
