@@ -232,13 +232,17 @@ def test_generator_step_bf16_compute_close_to_fp32():
             B1 = np.ones((B, 1), np.float32)
             tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [B1] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [B1] * 4 + \
                  [np.zeros(B, np.float32)] * 2 + [d['z1'], d['z2']]
-            h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']])
+            # teacher-forced at the Rounding layer like every model-level comparison (the fp32 run's anatomies)
+            h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']],
+                                             teacher_s=None if dt == 'fp32' else teacher)
+            if dt == 'fp32':
+                teacher = [model.last_factors['s1'].detach().clone(), model.last_factors['s2'].detach().clone()]
             res[dt] = {k: h.history[k][0] for k in h.history.keys()}
         assert P.set_conv_precision('fp32') == 'bf16'            # the bf16 build had switched the library
     finally:
         P.set_conv_precision('fp32')
     for k, v in res['fp32'].items():
-        # Segmentor / D losses go through the Rounding layer: a few flipped anatomy pixels move them a little more
-        tol = 5e-2 if k in ('loss', 'Segmentor_loss', 'D_Mask_loss') else 2e-2
+        # the discriminators' heads sum 373k bf16-rounded features of a randomly initialised network: looser there
+        tol = 5e-2 if k in ('loss', 'D_Mask_loss', 'D_Image1_loss', 'D_Image2_loss') else 2e-2
         assert abs(res['bf16'][k] - v) <= tol * max(1.0, abs(v)), (k, v, res['bf16'][k])
     assert any(abs(res['bf16'][k] - v) > 1e-6 for k, v in res['fp32'].items())      # and bf16 really ran
