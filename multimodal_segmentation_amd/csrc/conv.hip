@@ -982,7 +982,7 @@ static void launch_slab_reduce(const float* ws, float* tmp, float* dw, long n, i
     }
 }
 
-template <int BKT, int BNT, int WM, int WN>
+template <int BKT, int BNT, int WM, int WN, bool BF16 = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradParams q) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BKT / WM / 32, TN = BNT / WN / 32;
@@ -1092,18 +1092,40 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradPara
             if (more) load_stage(ps + PT);
             const float* A = Ap + cur * A_SZ;
             const float* D = Dp + cur * D_SZ;
+            if constexpr (BF16) {
+                // bf16 mode: the reduction index of this GEMM is the pixel, so an MFMA operand is 8 consecutive PIXELS of one
+                // column -- read down the fp32 [pixel][column] tile (8 conflict-free 4-byte reads), round to bf16 in registers
 #pragma unroll
-            for (int s = 0; s < PT / 2; ++s) {
-                float a[TM], b[TN];
+                for (int s = 0; s < PT / 16; ++s) {
+                    bf16x8 a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = A[(2 * s + lh) * BKT + a_col + i * 32];
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = D[(2 * s + lh) * BNT + b_col + j * 32];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                        for (int e = 0; e < 8; ++e) a[i][e] = (__bf16)A[(16 * s + 8 * lh + e) * BKT + a_col + i * 32];
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) b[j][e] = (__bf16)D[(16 * s + 8 * lh + e) * BNT + b_col + j * 32];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < PT / 2; ++s) {
+                    float a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = A[(2 * s + lh) * BKT + a_col + i * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = D[(2 * s + lh) * BNT + b_col + j * 32];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
             }
             if (more) store_stage(cur ^ 1);
             __syncthreads();
@@ -1129,7 +1151,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradPara
 template <int BKT, int BNT, int WM, int WN>
 static int launch_wgrad_fast(const WgradParams& q, int S, hipStream_t st) {
     dim3 grid(((q.c.K + BKT - 1) / BKT) * ((q.c.Cout + BNT - 1) / BNT) * S), block(WM * WN * 64);
-    hipLaunchKernelGGL((conv_wgrad_fast_kernel<BKT, BNT, WM, WN>), grid, block, 0, st, q);
+    if (g_conv_bf16) hipLaunchKernelGGL((conv_wgrad_fast_kernel<BKT, BNT, WM, WN, true>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_wgrad_fast_kernel<BKT, BNT, WM, WN>), grid, block, 0, st, q);
     return MMSEG_CHECK_LAUNCH();
 }
 

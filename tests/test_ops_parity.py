@@ -395,7 +395,7 @@ def _bf16(t):
     (3, 24, 24, 64, 0, 8, 1, 1, 'same', False)])
 def test_conv2d_bf16_precision(B, H, W, Cin, C2, Cout, k, stride, padding, ups):
     """mmseg_set_conv_precision(1): forward and data gradient == the fp64 oracle on bf16-rounded operands (the products are
-    then exact, only the fp32 accumulation differs); the weight gradient stays full fp32."""
+    then exact, only the fp32 accumulation differs); the same for the weight gradient."""
     dev = 'cuda'
     x1 = rnd(B, H // 2 if ups else H, W // 2 if ups else W, Cin, seed=1)
     x2 = rnd(B, H, W, C2, seed=2) if C2 else None
@@ -431,9 +431,9 @@ def test_conv2d_bf16_precision(B, H, W, Cin, C2, Cout, k, stride, padding, ups):
     _close(xp1.grad, gx[0], 'bf16 dgrad x1', 4e-4)
     if C2:
         _close(xp2.grad, gx[1], 'bf16 dgrad x2', 4e-4)
-    # weight gradient: fp32 path, unrounded operands
-    gw = torch.autograd.grad(O.conv2d(xin.detach(), wr, None, stride=stride, padding=padding), wr, D(cot))[0]
-    _close(wg, gw, 'wgrad (fp32)', 4e-4)
+    # weight gradient (fast path: channel counts divisible by 4): input patches and incoming gradient rounded to bf16
+    gw = torch.autograd.grad(O.conv2d(_bf16(xin.detach()), wr, None, stride=stride, padding=padding), wr, _bf16(cot))[0]
+    _close(wg, gw, 'bf16 wgrad', 4e-4)
     # and the rounding is really happening: the result differs from the unrounded oracle by more than fp32 noise
     y32 = O.conv2d(xin.detach(), D(w), D(b), stride=stride, padding=padding)
     if Cin >= 32 and Cout % 4 == 0:
