@@ -137,7 +137,7 @@ int mmseg_bn_infer_fold(const float* gamma, const float* beta, const float* mov_
                         float* scale, float* shift, int C, float eps, void* stream);
 int mmseg_bn_apply(const float* x, const float* scale, const float* shift, float* y, long M, int C, int relu, void* stream);
 int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean, const float* invstd,
-                 float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, void* stream);
+                 float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, int accumulate, void* stream);
 /* keras_contrib InstanceNormalization(axis=None) fused with SPADE_COND and LeakyReLU (layers/spade.py:7-33,51-54) */
 int mmseg_in_workspace_floats(int B);
 int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float* ws, int B,
@@ -151,7 +151,7 @@ long mmseg_dense_workspace_floats(int R, int K, int N);
 int mmseg_dense_fwd(const float* x, const float* w, const float* bias, float* y, float* ws, int R, int K, int N, int act,
                     float alpha, void* stream);
 int mmseg_dense_dgrad(const float* dy, const float* w, float* dx, int R, int K, int N, void* stream);
-int mmseg_dense_wgrad(const float* x, const float* dy, float* dw, int R, int K, int N, void* stream);
+int mmseg_dense_wgrad(const float* x, const float* dy, float* dw, int R, int K, int N, int accumulate, void* stream);
 
 /* ---- thin-plate-spline warp (csrc/tps.hip): layers/stn_spline.py:36-67 + interpolate_spline.py + resampler --- */
 int mmseg_tps_workspace_floats(int B);
@@ -206,6 +206,13 @@ int mmseg_adam(float* p, const float* g, float* m, float* v, long n, float lr_t,
 long mmseg_spectral_workspace_floats(int K, int N);
 int mmseg_spectral_fwd(const float* w, const float* u0, float* loss, float* sgn, float* ws, int K, int N, float alpha, void* stream);
 int mmseg_spectral_grad(const float* w, const float* sgn, float scale, long n, float* dw, void* stream);
+/* the penalties of up to 4 matrices (the 4 down-sample blocks of one discriminator, models/discriminator.py:24-41) in one batch
+ * of launches: loss[i], sgn[i]; ws = the per-matrix workspaces back to back; and their gradients accumulated into dw_i */
+int mmseg_spectral_fwd4(const float* w0, const float* w1, const float* w2, const float* w3, const float* u0, const float* u1,
+                        const float* u2, const float* u3, float* loss, float* sgn, float* ws, int n, int K0, int N0, int K1, int N1,
+                        int K2, int N2, int K3, int N3, float alpha, void* stream);
+int mmseg_spectral_grad4(const float* w0, const float* w1, const float* w2, const float* w3, const float* sgn, float* dw0, float* dw1,
+                         float* dw2, float* dw3, int n, long n0, long n1, long n2, long n3, float scale, void* stream);
 
 #ifdef __cplusplus
 }

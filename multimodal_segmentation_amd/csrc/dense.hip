@@ -143,13 +143,13 @@ __global__ void dense_dgrad_kernel(const float* __restrict__ dy, const float* __
 
 // dW[k][n] = sum_b x[b][k] * dy[b][n]
 __global__ void dense_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                   int R, int K, int N) {
+                                   int R, int K, int N, int accumulate) {
     const long total = (long)K * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k = i / N, n = i - (long)k * N;
         float a = 0.f;
         for (int b = 0; b < R; ++b) a += x[(size_t)b * K + k] * dy[(size_t)b * N + n];
-        dw[i] = a;
+        dw[i] = accumulate ? dw[i] + a : a;
     }
 }
 
@@ -190,11 +190,11 @@ int mmseg_dense_dgrad(const float* dy, const float* w, float* dx, int R, int K, 
     hipLaunchKernelGGL(dense_dgrad_kernel, dim3((K + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, w, dx, R, K, N);
     return MMSEG_CHECK_LAUNCH();
 }
-int mmseg_dense_wgrad(const float* x, const float* dy, float* dw, int R, int K, int N, void* stream) {
+int mmseg_dense_wgrad(const float* x, const float* dy, float* dw, int R, int K, int N, int accumulate, void* stream) {
     if (R < 1 || R > 32) return (int)hipErrorInvalidValue;
     long blocks = ((long)K * N + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(dense_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dw, R, K, N);
+    hipLaunchKernelGGL(dense_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dw, R, K, N, accumulate);
     return MMSEG_CHECK_LAUNCH();
 }
 

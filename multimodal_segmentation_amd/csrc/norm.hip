@@ -183,13 +183,14 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 // finalize backward sums: dbeta, dgamma and per-channel coefficients  dx = A*g + Bc*x + Cc
 __global__ void bn_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                    float* __restrict__ coef /* [3][C] */, int nblk, int C, long M) {
+                                    float* __restrict__ coef /* [3][C] */, int nblk, int C, long M, int accumulate) {
     __shared__ float sm[512];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     float s1, s2;
     reduce_partials_64x4(part, nblk, C, c, lane, s1, s2, sm);
     if (c >= C || lane != 0) return;
-    dbeta[c] = s1; dgamma[c] = s2;
+    if (accumulate) { dbeta[c] += s1; dgamma[c] += s2; }      // straight into the gradient arena
+    else { dbeta[c] = s1; dgamma[c] = s2; }
     const float invM = 1.f / (float)M, is = invstd[c], ga = gamma[c], mu = mean[c];
     const float A = ga * is;
     const float Bc = -ga * is * is * s2 * invM;
@@ -370,7 +371,7 @@ int mmseg_bn_apply(const float* x, const float* scale, const float* shift, float
 }
 // coef: 3*C floats of scratch
 int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean, const float* invstd,
-                 float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, void* stream) {
+                 float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, int accumulate, void* stream) {
     if (C & 3) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     int nblk;
@@ -383,7 +384,7 @@ int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* g
         const long rpb = (M + nblk - 1) / nblk;
         hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
     }
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M, accumulate);
     const long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y, x, (const float*)coef, dx, n4, C / 4, relu);
     return MMSEG_CHECK_LAUNCH();

@@ -94,6 +94,104 @@ __global__ void spec_grad_kernel(const float* __restrict__ w, const float* __res
     }
 }
 
+// ---- the same, for up to 4 independent matrices per launch (the 4 down-sample blocks of one discriminator) --------------
+// Each single-matrix step above is a tiny launch (the largest W is 4096 x 512); a discriminator's regulariser is 4 x 14 of
+// them and an iteration evaluates 7 discriminators.  Batched: blockIdx.z (or .y) selects the matrix, grids cover the largest.
+#define SPEC_MAXP 4
+struct SpecBatch {
+    const float* w[SPEC_MAXP];
+    const float* u0[SPEC_MAXP];
+    float* ws[SPEC_MAXP];          // per-matrix workspace: part | u | v | apart | sigma  (mmseg_spectral_workspace_floats)
+    int K[SPEC_MAXP], N[SPEC_MAXP];
+};
+__device__ __forceinline__ long spec_part_floats_dev(int K, int N) { const long a = (long)SPEC_KS * N; return a > K ? a : K; }
+__global__ void spec_gemv_t_multi_kernel(SpecBatch b, int first) {
+    const int z = blockIdx.z, K = b.K[z], N = b.N[z];
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* w = b.w[z];
+    float* part = b.ws[z];
+    const float* u = first ? b.u0[z] : part + spec_part_floats_dev(K, N);
+    const int kper = (K + SPEC_KS - 1) / SPEC_KS;
+    const int k0 = blockIdx.y * kper, k1 = min(K, k0 + kper);
+    float a = 0.f;
+    for (int k = k0; k < k1; ++k) a += w[(size_t)k * N + n] * u[k];
+    part[(size_t)blockIdx.y * N + n] = a;
+}
+__global__ void spec_gemv_n_multi_kernel(SpecBatch b) {
+    const int z = blockIdx.y, K = b.K[z], N = b.N[z];
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= K) return;
+    const float* w = b.w[z];
+    float* part = b.ws[z];
+    const float* v = part + spec_part_floats_dev(K, N) + K;
+    float a = 0.f;
+    for (int n = lane; n < N; n += 64) a += w[(size_t)k * N + n] * v[n];
+    a = wave_sum(a);
+    if (lane == 0) part[k] = a;
+}
+// which = 0: v = normalise(sum_s part[s][:N]);  which = 1: u = normalise(part[:K]), sigma = the norm
+__global__ void spec_normalize_multi_kernel(SpecBatch b, int which) {
+    __shared__ float red[17];
+    const int z = blockIdx.x, K = b.K[z], N = b.N[z];
+    float* part = b.ws[z];
+    float* u = part + spec_part_floats_dev(K, N);
+    float* v = u + K;
+    float* sigma = v + N + 1024;
+    const int S = which ? 1 : SPEC_KS, n = which ? K : N;
+    float* vec = which ? u : v;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += part[(size_t)s * n + i];
+        vec[i] = a;
+        ss += a * a;
+    }
+    ss = block_sum(ss, red);
+    const float nrm = sqrtf(ss);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) vec[i] = vec[i] / nrm;
+    if (threadIdx.x == 0 && which) sigma[0] = nrm;
+}
+__global__ void spec_abs_partial_multi_kernel(SpecBatch b) {
+    __shared__ float red[17];
+    const int z = blockIdx.y, K = b.K[z], N = b.N[z];
+    const long n = (long)K * N;
+    const float* w = b.w[z];
+    float* apart = b.ws[z] + spec_part_floats_dev(K, N) + K + N;
+    float a = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a += fabsf(w[i]);
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) apart[blockIdx.x] = a;
+}
+__global__ void spec_final_multi_kernel(SpecBatch b, float alpha, float* __restrict__ loss, float* __restrict__ sgn) {
+    __shared__ float red[17];
+    const int z = blockIdx.x, K = b.K[z], N = b.N[z];
+    const long n = (long)K * N;
+    const float* apart = b.ws[z] + spec_part_floats_dev(K, N) + K + N;
+    const float* sigma = apart + 1024;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) a += apart[i];
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) {
+        const float d = 1.f - 1.f / sigma[0];
+        loss[z] = alpha * fabsf(d) * a / (float)n;
+        sgn[z] = (alpha / (float)n) * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    }
+}
+struct SpecGradBatch { const float* w[SPEC_MAXP]; float* dw[SPEC_MAXP]; long n[SPEC_MAXP]; };
+// dW[z] += scale * sgn[z] * sign(W[z])
+__global__ void spec_grad_multi_kernel(SpecGradBatch b, const float* __restrict__ sgn, float scale) {
+    const int z = blockIdx.y;
+    const float s = sgn[z] * scale;
+    const float* w = b.w[z];
+    float* dw = b.dw[z];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < b.n[z]; i += (long)gridDim.x * blockDim.x) {
+        const float x = w[i];
+        dw[i] += x > 0.f ? s : (x < 0.f ? -s : 0.f);
+    }
+}
+
 extern "C" {
 
 int mmseg_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, void* stream) {
@@ -129,6 +227,59 @@ int mmseg_spectral_fwd(const float* w, const float* u0, float* loss, float* sgn,
     const long n = (long)K * N;
     hipLaunchKernelGGL(spec_abs_partial_kernel, dim3(1024), dim3(256), 0, st, w, n, apart);
     hipLaunchKernelGGL(spec_final_kernel, dim3(1), dim3(256), 0, st, (const float*)apart, 1024, (const float*)sigma, n, alpha, loss, sgn);
+    return MMSEG_CHECK_LAUNCH();
+}
+// The Spectral penalties of up to 4 matrices in one batch of launches (14 instead of 14 per matrix): loss[i], sgn[i] for
+// matrix i.  ws = the matrices' workspaces back to back (mmseg_spectral_workspace_floats(K_i, N_i) floats each).
+int mmseg_spectral_fwd4(const float* w0, const float* w1, const float* w2, const float* w3, const float* u0, const float* u1,
+                        const float* u2, const float* u3, float* loss, float* sgn, float* ws, int n, int K0, int N0, int K1, int N1,
+                        int K2, int N2, int K3, int N3, float alpha, void* stream) {
+    if (n < 1 || n > SPEC_MAXP) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    SpecBatch b;
+    const float* ws_[4] = {w0, w1, w2, w3};
+    const float* us_[4] = {u0, u1, u2, u3};
+    const int Ks[4] = {K0, K1, K2, K3}, Ns[4] = {N0, N1, N2, N3};
+    int maxK = 0, maxN = 0;
+    long off = 0;
+    for (int i = 0; i < SPEC_MAXP; ++i) {
+        const int j = i < n ? i : 0;
+        b.w[i] = ws_[j]; b.u0[i] = us_[j]; b.K[i] = Ks[j]; b.N[i] = Ns[j];
+        b.ws[i] = ws + (i < n ? off : 0);
+        if (i < n) {
+            if (Ks[i] < 1 || Ns[i] < 1) return (int)hipErrorInvalidValue;
+            off += mmseg_spectral_workspace_floats(Ks[i], Ns[i]);
+            if (Ks[i] > maxK) maxK = Ks[i];
+            if (Ns[i] > maxN) maxN = Ns[i];
+        }
+    }
+    for (int it = 0; it < 3; ++it) {
+        hipLaunchKernelGGL(spec_gemv_t_multi_kernel, dim3((maxN + 255) / 256, SPEC_KS, n), dim3(256), 0, st, b, it == 0 ? 1 : 0);
+        hipLaunchKernelGGL(spec_normalize_multi_kernel, dim3(n), dim3(1024), 0, st, b, 0);
+        hipLaunchKernelGGL(spec_gemv_n_multi_kernel, dim3((maxK + 3) / 4, n), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(spec_normalize_multi_kernel, dim3(n), dim3(1024), 0, st, b, 1);
+    }
+    hipLaunchKernelGGL(spec_abs_partial_multi_kernel, dim3(1024, n), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(spec_final_multi_kernel, dim3(n), dim3(256), 0, st, b, alpha, loss, sgn);
+    return MMSEG_CHECK_LAUNCH();
+}
+// dW_i += scale * sgn[i] * sign(W_i): the penalties' gradients accumulated straight into the gradient arena
+int mmseg_spectral_grad4(const float* w0, const float* w1, const float* w2, const float* w3, const float* sgn, float* dw0, float* dw1,
+                         float* dw2, float* dw3, int n, long n0, long n1, long n2, long n3, float scale, void* stream) {
+    if (n < 1 || n > SPEC_MAXP) return (int)hipErrorInvalidValue;
+    SpecGradBatch b;
+    const float* ws_[4] = {w0, w1, w2, w3};
+    float* ds_[4] = {dw0, dw1, dw2, dw3};
+    const long ns[4] = {n0, n1, n2, n3};
+    long mx = 0;
+    for (int i = 0; i < SPEC_MAXP; ++i) {
+        const int j = i < n ? i : 0;
+        b.w[i] = ws_[j]; b.dw[i] = ds_[j]; b.n[i] = i < n ? ns[i] : 0;
+        if (b.n[i] > mx) mx = b.n[i];
+    }
+    long blocks = (mx + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(spec_grad_multi_kernel, dim3((unsigned)blocks, n), dim3(256), 0, (hipStream_t)stream, b, sgn, scale);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_spectral_grad(const float* w, const float* sgn, float scale, long n, float* dw, void* stream) {

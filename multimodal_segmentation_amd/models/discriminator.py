@@ -42,13 +42,15 @@ class DiscriminatorModel(nn.Model):
     def regulariser_losses(self, accumulate_grad=True):
         """Sum of the Spectral penalties of the down-sample blocks; their gradient is accumulated into the gradient
         arena when the model is trainable.  -> list of device scalars."""
+        names = ['c%d' % (i + 1) for i in range(len(self.strides))]
         out = []
-        for i in range(len(self.strides)):
-            w = self.params['c%d/kernel' % (i + 1)]
-            loss, sgn = ops.spectral_reg(w.data, self.params['c%d/u0' % (i + 1)].data, 10.0)
+        for g0 in range(0, len(names), 4):            # up to 4 kernels per batch of launches
+            grp = names[g0:g0 + 4]
+            ws_ = [self.params[n + '/kernel'] for n in grp]
+            loss, sgn = ops.spectral_reg_multi([w.data for w in ws_], [self.params[n + '/u0'].data for n in grp], 10.0)
             if accumulate_grad and self.trainable:
-                ops.axpby(w.grad, ops.spectral_reg_grad(w.data, sgn), out=w.grad)
-            out.append(loss)
+                ops.spectral_reg_grad_accumulate([w.data for w in ws_], sgn, [w.grad for w in ws_])
+            out += [loss[i:i + 1] for i in range(len(grp))]
         return out
 
 

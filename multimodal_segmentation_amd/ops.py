@@ -63,9 +63,14 @@ _weight_version = [0]
 _wprep_cache = {}
 
 
+_bn_state_version = [0]      # bumped whenever BatchNorm moving statistics may have changed (training-mode forward)
+_bnfold_cache = {}
+
+
 def bump_weight_version():
     """Invalidate the cached weight re-layouts (called whenever weights change: optimiser step, set_weights)."""
     _weight_version[0] += 1
+    _bn_state_version[0] += 1
 
 
 def _wprep(w, KH, KW, Cin, Cout, mode, wkey=None):
@@ -238,8 +243,17 @@ def conv2d_bn_infer(x, w, cbias, gamma, beta, mov_mean, mov_var, relu=False, x2=
     KH, KW, Cin, Cout = w.shape
     assert Cin == C1 + C2
     Ho, Wo, ph, pw = _conv_geometry(H, W, KH, KW, 1, 'same')
-    ss = _new((2, Cout), x1)
-    N.call('mmseg_bn_infer_fold', gamma, beta, mov_mean, mov_var, cbias, ss[0], ss[1], Cout, BN_EPS)
+    # folded scale / bias: cached per layer until the weights or the moving statistics change (a pool evaluates every
+    # encoder layer four times per iteration with the same parameters)
+    key = (wkey, gamma.data_ptr(), 'bnfold')
+    ent = _bnfold_cache.get(key) if wkey is not None else None
+    if ent is not None and ent[0] == (_weight_version[0], _bn_state_version[0]):
+        ss = ent[1]
+    else:
+        ss = ent[1] if ent is not None else _new((2, Cout), x1)
+        N.call('mmseg_bn_infer_fold', gamma, beta, mov_mean, mov_var, cbias, ss[0], ss[1], Cout, BN_EPS)
+        if wkey is not None:
+            _bnfold_cache[key] = ((_weight_version[0], _bn_state_version[0]), ss)
     y = _new((B, Ho, Wo, Cout), x1)
     wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
     N.call('mmseg_conv2d_fwd_scaled', x1, x2, w, wt, ss[1], ss[0], y, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, 1, ph, pw,
@@ -264,6 +278,7 @@ def conv2d(x, w, bias=None, stride=1, padding='same', act=None, alpha=0.0, x2=No
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, gamma, beta, mov_mean, mov_var, relu, ggrad, bgrad):
+        _bn_state_version[0] += 1          # the moving statistics are about to change: folded inference parameters are stale
         x = _c(x)
         C = x.shape[-1]
         M = x.numel() // C
@@ -285,15 +300,19 @@ class _BatchNormTrain(torch.autograd.Function):
         C = x.shape[-1]
         M = x.numel() // C
         dx = _new(x.shape, x)
-        tmp = _ws('bn_dgb', 2 * C, x.device)
-        dgamma, dbeta = tmp[:C], tmp[C:2 * C]
         coef = _ws('bn_coef', 3 * C, x.device)
         ws = _ws('norm', N.call('mmseg_norm_workspace_floats', C), x.device)
-        N.call('mmseg_bn_bwd', dy, y, x, ctx.gamma, stats[0], stats[1], dx, dgamma, dbeta, coef, ws, M, C, int(ctx.relu))
-        if ctx.ggrad is not None:
-            _accumulate(ctx.ggrad, dgamma)
-        if ctx.bgrad is not None:
-            _accumulate(ctx.bgrad, dbeta)
+        if ctx.ggrad is not None and ctx.bgrad is not None:
+            # the final reduction adds dgamma / dbeta straight into the gradient-arena views
+            N.call('mmseg_bn_bwd', dy, y, x, ctx.gamma, stats[0], stats[1], dx, ctx.ggrad, ctx.bgrad, coef, ws, M, C, int(ctx.relu), 1)
+        else:
+            tmp = _ws('bn_dgb', 2 * C, x.device)
+            dgamma, dbeta = tmp[:C], tmp[C:2 * C]
+            N.call('mmseg_bn_bwd', dy, y, x, ctx.gamma, stats[0], stats[1], dx, dgamma, dbeta, coef, ws, M, C, int(ctx.relu), 0)
+            if ctx.ggrad is not None:
+                _accumulate(ctx.ggrad, dgamma)
+            if ctx.bgrad is not None:
+                _accumulate(ctx.bgrad, dbeta)
         _grad_done(ctx.ggrad, ctx.bgrad)
         return (dx,) + (None,) * 8
 
@@ -474,11 +493,9 @@ class _Dense(torch.autograd.Function):
                 r = min(_DENSE_ROWS, R - r0)
                 N.call('mmseg_dense_dgrad', g[r0:r0 + r], w, dx[r0:r0 + r], r, K, Nn)
         if ctx.wgrad is not None:
-            dw = _ws('dw_tmp', w.numel(), x.device)[:w.numel()]
-            for r0 in range(0, R, _DENSE_ROWS):
+            for r0 in range(0, R, _DENSE_ROWS):          # accumulates straight into the gradient-arena view
                 r = min(_DENSE_ROWS, R - r0)
-                N.call('mmseg_dense_wgrad', x[r0:r0 + r], g[r0:r0 + r], dw, r, K, Nn)
-                _accumulate(ctx.wgrad.view(-1), dw)
+                N.call('mmseg_dense_wgrad', x[r0:r0 + r], g[r0:r0 + r], ctx.wgrad.view(-1), r, K, Nn, 1)
         if ctx.bgrad is not None:
             ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', R, Nn), x.device)
             N.call('mmseg_colsum', g, ctx.bgrad, ws, R, Nn, 1.0, 1)
@@ -884,6 +901,27 @@ def spectral_reg(w, u0, alpha=10.0):
     ws = _ws('spectral', N.call('mmseg_spectral_workspace_floats', K, Nn), w.device)
     N.call('mmseg_spectral_fwd', w, u0, loss, sgn, ws, K, Nn, float(alpha))
     return loss, sgn
+
+
+def spectral_reg_multi(ws_, u0s, alpha=10.0):
+    """The Spectral penalties of up to 4 kernels in one batch of launches -> (loss[n], sgn[n])."""
+    n = len(ws_)
+    assert 1 <= n <= 4 and len(u0s) == n
+    dims = [(w.numel() // w.shape[-1], w.shape[-1]) for w in ws_]
+    loss, sgn = _new((n,), ws_[0]), _new((n,), ws_[0])
+    need = sum(N.call('mmseg_spectral_workspace_floats', K, Nn) for K, Nn in dims)
+    ws = _ws('spectral', need, ws_[0].device)
+    pad = lambda lst, fill: list(lst) + [fill] * (4 - n)
+    flat = [v for d in pad(dims, dims[0]) for v in d]
+    N.call('mmseg_spectral_fwd4', *pad(ws_, ws_[0]), *pad(u0s, u0s[0]), loss, sgn, ws, n, *flat, float(alpha))
+    return loss, sgn
+
+
+def spectral_reg_grad_accumulate(ws_, sgn, grads, scale=1.0):
+    """grads[i] += scale * d penalty_i / d W_i  (one launch)"""
+    n = len(ws_)
+    pad = lambda lst, fill: list(lst) + [fill] * (4 - n)
+    N.call('mmseg_spectral_grad4', *pad(ws_, ws_[0]), sgn, *pad(grads, grads[0]), n, *pad([w.numel() for w in ws_], 0), float(scale))
 
 
 def spectral_reg_grad(w, sgn, scale=1.0):

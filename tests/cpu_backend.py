@@ -289,13 +289,16 @@ def bn_apply(x, scale, shift, y, M, C, relu):
     y.copy_(v.reshape(y.shape)); return 0
 
 
-def bn_bwd(dy, y, x, gamma, mean, invstd, dx, dgamma, dbeta, coef, ws, M, C, relu):
+def bn_bwd(dy, y, x, gamma, mean, invstd, dx, dgamma, dbeta, coef, ws, M, C, relu, accumulate):
     g = dy.reshape(M, C)
     if relu:
         g = g * (y.reshape(M, C) > 0).to(g.dtype)
     xh = (x.reshape(M, C) - mean) * invstd
     db, dg = g.sum(0), (g * xh).sum(0)
-    dbeta.copy_(db); dgamma.copy_(dg)
+    if accumulate:
+        dbeta.add_(db); dgamma.add_(dg)
+    else:
+        dbeta.copy_(db); dgamma.copy_(dg)
     dx.copy_((gamma * invstd * (g - db / M - xh * dg / M)).reshape(dx.shape)); return 0
 
 
@@ -354,8 +357,13 @@ def dense_dgrad(dy, w, dx, R, K, N):
     dx.copy_(dy.reshape(R, N) @ w.reshape(K, N).t()); return 0
 
 
-def dense_wgrad(x, dy, dw, R, K, N):
-    dw.copy_((x.reshape(R, K).t() @ dy.reshape(R, N)).reshape(dw.shape)); return 0
+def dense_wgrad(x, dy, dw, R, K, N, accumulate):
+    v = (x.reshape(R, K).t() @ dy.reshape(R, N)).reshape(dw.shape)
+    if accumulate:
+        dw.add_(v)
+    else:
+        dw.copy_(v)
+    return 0
 
 
 def tps_workspace_floats(B):
@@ -482,6 +490,18 @@ def spectral_fwd(w, u0, loss, sgn, ws, K, N, alpha):
     d = 1 - 1 / sigma
     loss.copy_((alpha * d.abs() * x.abs().mean()).reshape(1))
     sgn.copy_((alpha / x.numel() * torch.sign(d)).reshape(1)); return 0
+
+
+def spectral_fwd4(w0, w1, w2, w3, u0, u1, u2, u3, loss, sgn, ws, n, K0, N0, K1, N1, K2, N2, K3, N3, alpha):
+    for i, (w, u, K, N_) in enumerate(((w0, u0, K0, N0), (w1, u1, K1, N1), (w2, u2, K2, N2), (w3, u3, K3, N3))[:n]):
+        spectral_fwd(w, u, loss[i:i + 1], sgn[i:i + 1], None, K, N_, alpha)
+    return 0
+
+
+def spectral_grad4(w0, w1, w2, w3, sgn, d0, d1, d2, d3, n, n0, n1, n2, n3, scale):
+    for i, (w, d) in enumerate(((w0, d0), (w1, d1), (w2, d2), (w3, d3))[:n]):
+        d.add_(torch.sign(w) * sgn[i] * scale)
+    return 0
 
 
 def spectral_grad(w, sgn, scale, n, dw):

@@ -438,3 +438,25 @@ def test_conv2d_bf16_precision(B, H, W, Cin, C2, Cout, k, stride, padding, ups):
     y32 = O.conv2d(xin.detach(), D(w), D(b), stride=stride, padding=padding)
     if Cin >= 32 and Cout % 4 == 0:
         assert (y.detach().cpu().double() - y32).abs().max() > 1e-4 * y32.abs().max()
+
+
+@pytest.mark.parametrize('n', [4, 2])
+def test_spectral_reg_multi(n, device):
+    """the Spectral penalties of a discriminator's down-sample blocks in one batch of launches == one matrix at a time"""
+    shapes = [(4, 4, 4, 64), (4, 4, 64, 128), (4, 4, 128, 256), (4, 4, 256, 512)][:n]
+    ws_, u0s, refs, grefs = [], [], [], []
+    for i, shp in enumerate(shapes):
+        w = rnd(*shp, seed=40 + i, scale=0.05)
+        u0 = torch.rand(shp[0] * shp[1] * shp[2], 1, generator=torch.Generator().manual_seed(50 + i)) * 2 - 1
+        wr = w.clone().double().requires_grad_(True)
+        ref = O.spectral_reg(wr, u0.double(), 10.0)
+        refs.append(ref.reshape(1))
+        grefs.append(torch.autograd.grad(ref, wr)[0])
+        ws_.append(w.to(device))
+        u0s.append(u0.to(device))
+    loss, sgn = P.spectral_reg_multi(ws_, u0s, 10.0)
+    _close(loss, torch.cat(refs), 'losses', 1e-4)
+    grads = [torch.full_like(w, 0.5) for w in ws_]             # accumulates into existing gradients
+    P.spectral_reg_grad_accumulate(ws_, sgn, grads)
+    for g, gr in zip(grads, grefs):
+        _close(g - 0.5, gr, 'grad', 1e-5)
