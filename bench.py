@@ -201,7 +201,7 @@ def main():
     ap.add_argument('--model', default='dafnet', choices=['dafnet', 'mmsdnet'],
                     help="mmsdnet: the MMSDNet iteration (mmsdnet_executor.py:238-331) instead of the headline DAFNet one")
     ap.add_argument('--l_mix', type=float, default=1.0)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f16'],
                     help='bf16: bf16 MFMA operands (fp32 accumulation, fp32 tensors in HBM, fp32 weight gradients) -- configs #3/#5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
@@ -246,7 +246,7 @@ def main():
     cfg['batch_size'] = args.batch
     cfg['l_mix'] = args.l_mix
     cfg['n_pairs'] = 1
-    cfg['compute_dtype'] = 'bf16' if args.dtype == 'bf16' else 'fp32'
+    cfg['compute_dtype'] = {'f32': 'fp32', 'bf16': 'bf16', 'f16': 'fp16'}[args.dtype]
     cfg['folder'] = '/tmp/mmseg_bench'
     conf = EasyDict(cfg)
 
@@ -336,9 +336,9 @@ def main():
         k = summ.get('conv_fwd_kernel')
         if k:
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
-            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
+            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype in ('bf16', 'f16') else FP32_MFMA_PEAK_TFLOPS
             line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (implicit-GEMM %s MFMA; forward + data-gradient launches)'
-                                                           % ('bf16 (fp32 tensors in HBM, fp32 accumulation)' if args.dtype == 'bf16' else 'fp32'),
+                                                           % ('%s (fp32 tensors in HBM, fp32 accumulation)' % args.dtype if args.dtype != 'f32' else 'fp32'),
                                 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                                 'traffic': traffic.get('conv_fwd', {}).get('hbm_bytes_per_launch'),
                                 'algorithmic_bytes_per_launch': k['bytes'] / k['launches'],

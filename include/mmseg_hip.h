@@ -44,8 +44,8 @@ extern "C" {
 int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, float* y, float* y2,
                      int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                      int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, void* stream);
-/* precision of the fast-path forward / data-gradient convolutions (process-wide): 0 = fp32 MFMA (default), 1 = operands rounded
- * to bf16 (RNE) + v_mfma_f32_32x32x16_bf16 with fp32 accumulation; HBM tensors, weight gradients and everything else stay fp32
+/* precision of the fast-path convolutions -- forward, data gradient, weight gradient (process-wide): 0 = fp32 MFMA (default),
+ * 1 = operands rounded to bf16 (RNE) + v_mfma_f32_32x32x16_bf16, 2 = fp16 + v_mfma_f32_32x32x16_f16, both with fp32 accumulation; HBM tensors, weight gradients and everything else stay fp32
  * (BASELINE configs #3 / #5: reduced-precision compute with fp32 master weights and fp32 gradient all-reduce).
  * mmseg_set_conv_precision returns the previous mode. */
 int mmseg_set_conv_precision(int mode);

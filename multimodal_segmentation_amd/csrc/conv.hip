@@ -50,6 +50,19 @@ struct ConvParams {
 #define BK 32
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// 16-bit MFMA operand types of the reduced-precision modes (mmseg_set_conv_precision): PREC 1 = bf16, 2 = fp16
+template <int PREC> struct LowPrec;
+template <> struct LowPrec<1> {
+    typedef __bf16 T; typedef bf16x4 V4; typedef bf16x8 V8;
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct LowPrec<2> {
+    typedef _Float16 T; typedef f16x4 V4; typedef f16x8 V8;
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct LowPrec<0> { typedef float T; typedef f32x4 V4; typedef f32x4 V8; };   // unused placeholder
 #define AS_LD (BK + 4)
 
 __device__ __forceinline__ f32x4 gather_tap4(const ConvParams& p, int b, int hb, int wb, int kh, int kw, int c) {
@@ -282,7 +295,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
-template <int BM, int BN, int WM, int WN, bool BF16 = false>
+template <int BM, int BN, int WM, int WN, int PREC = 0>
 __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bid, const int nblk) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -295,6 +308,10 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
     // are rows of 32 bf16 = 64 bytes (4 chunks of 16 bytes, chunk index XOR-swizzled with (row >> 1) & 3: conflict-free for
     // the 8-byte stores and the 16-byte operand reads alike), products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
     // LD counts 4-byte words per row.
+    constexpr bool BF16 = PREC != 0;         // any 16-bit operand mode (bf16 or fp16): same tile geometry
+    typedef typename LowPrec<PREC>::T LT;
+    typedef typename LowPrec<PREC>::V4 LV4;
+    typedef typename LowPrec<PREC>::V8 LV8;
     constexpr int LD = BF16 ? BK / 2 : BK;
     constexpr int A_SZ = BM * LD, B_SZ = BN * LD;
 
@@ -405,14 +422,14 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
 #pragma unroll
             for (int j = 0; j < A_F4; ++j) {
                 const int row = ar0 + j * A_RPP;
-                bf16x4 v = {(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
-                *reinterpret_cast<bf16x4*>(&A[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)]) = v;
+                LV4 v = {(LT)ra[j][0], (LT)ra[j][1], (LT)ra[j][2], (LT)ra[j][3]};
+                *reinterpret_cast<LV4*>(&A[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)]) = v;
             }
 #pragma unroll
             for (int j = 0; j < B_F4; ++j) {
                 const int row = ar0 + j * A_RPP;
-                bf16x4 v = {(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
-                if (row < BN) *reinterpret_cast<bf16x4*>(&Bt[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)]) = v;
+                LV4 v = {(LT)rb[j][0], (LT)rb[j][1], (LT)rb[j][2], (LT)rb[j][3]};
+                if (row < BN) *reinterpret_cast<LV4*>(&Bt[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)]) = v;
             }
         } else {
 #pragma unroll
@@ -454,18 +471,18 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
         if constexpr (BF16) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {            // two k-steps of 16; lane half lh supplies k = 16 q + 8 lh + [0, 8)
-                bf16x8 a[TM], b[TN];
+                LV8 a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    a[i] = *reinterpret_cast<const bf16x8*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ (((a_row + i * 32) >> 1) & 3))]);
+                    a[i] = *reinterpret_cast<const LV8*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ (((a_row + i * 32) >> 1) & 3))]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    b[j] = *reinterpret_cast<const bf16x8*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ (((b_col + j * 32) >> 1) & 3))]);
+                    b[j] = *reinterpret_cast<const LV8*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ (((b_col + j * 32) >> 1) & 3))]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[q % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[q % NACC][i][j], 0, 0, 0);
+                        acc[q % NACC][i][j] = LowPrec<PREC>::mfma(a[i], b[j], acc[q % NACC][i][j]);
             }
         } else {
 #pragma unroll
@@ -522,22 +539,22 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool BF16 = false>
+template <int BM, int BN, int WM, int WN, int PREC = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
-    conv_fast_body<BM, BN, WM, WN, BF16>(p, blockIdx.x, gridDim.x);
+    conv_fast_body<BM, BN, WM, WN, PREC>(p, blockIdx.x, gridDim.x);
 }
 // up to 4 independent convolutions of one tile configuration in a single launch (blockIdx.y selects the problem): the
 // parity classes of a strided convolution's data gradient are each too small to fill 256 CUs
 struct ConvBatch { ConvParams p[4]; int nblk[4]; };
 // 0: fp32 MFMA (default); 1: the fast-path forward / data-gradient convolutions round their operands to bf16 and use the bf16
 // MFMA with fp32 accumulation (activations, weights and weight gradients stay fp32 in HBM) -- mmseg_set_conv_precision
-static int g_conv_bf16 = 0;
-template <int BM, int BN, int WM, int WN, bool BF16 = false>
+static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
+template <int BM, int BN, int WM, int WN, int PREC = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fast_batched_kernel(ConvBatch pb) {
     const int z = blockIdx.y;
     const int nb = pb.nblk[z];
     if ((int)blockIdx.x >= nb) return;
-    conv_fast_body<BM, BN, WM, WN, BF16>(pb.p[z], blockIdx.x, nb);
+    conv_fast_body<BM, BN, WM, WN, PREC>(pb.p[z], blockIdx.x, nb);
 }
 template <int BM, int BN, int WM, int WN>
 static int launch_fast_batched(ConvBatch& pb, int n, hipStream_t st) {
@@ -548,7 +565,8 @@ static int launch_fast_batched(ConvBatch& pb, int n, hipStream_t st) {
         if (pb.nblk[z] > mx) mx = pb.nblk[z];
     }
     for (int z = n; z < 4; ++z) pb.nblk[z] = 0;
-    if (g_conv_bf16) hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN, true>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
+    if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN, 1>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
+    else if (g_conv_bf16 == 2) hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN, 2>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
     else hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
     return MMSEG_CHECK_LAUNCH();
 }
@@ -556,7 +574,8 @@ static int launch_fast_batched(ConvBatch& pb, int n, hipStream_t st) {
 template <int BM, int BN, int WM, int WN>
 static int launch_fast(const ConvParams& p, hipStream_t st) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
-    if (g_conv_bf16) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, true>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
+    if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, 1>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
+    else if (g_conv_bf16 == 2) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, 2>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
     else hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
     return MMSEG_CHECK_LAUNCH();
 }
@@ -982,7 +1001,7 @@ static void launch_slab_reduce(const float* ws, float* tmp, float* dw, long n, i
     }
 }
 
-template <int BKT, int BNT, int WM, int WN, bool BF16 = false>
+template <int BKT, int BNT, int WM, int WN, int PREC = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradParams q) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BKT / WM / 32, TN = BNT / WN / 32;
@@ -1092,25 +1111,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradPara
             if (more) load_stage(ps + PT);
             const float* A = Ap + cur * A_SZ;
             const float* D = Dp + cur * D_SZ;
-            if constexpr (BF16) {
+            if constexpr (PREC != 0) {
+                typedef typename LowPrec<PREC>::T LT;
+                typedef typename LowPrec<PREC>::V8 LV8;
                 // bf16 mode: the reduction index of this GEMM is the pixel, so an MFMA operand is 8 consecutive PIXELS of one
                 // column -- read down the fp32 [pixel][column] tile (8 conflict-free 4-byte reads), round to bf16 in registers
 #pragma unroll
                 for (int s = 0; s < PT / 16; ++s) {
-                    bf16x8 a[TM], b[TN];
+                    LV8 a[TM], b[TN];
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) a[i][e] = (__bf16)A[(16 * s + 8 * lh + e) * BKT + a_col + i * 32];
+                        for (int e = 0; e < 8; ++e) a[i][e] = (LT)A[(16 * s + 8 * lh + e) * BKT + a_col + i * 32];
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) b[j][e] = (__bf16)D[(16 * s + 8 * lh + e) * BNT + b_col + j * 32];
+                        for (int e = 0; e < 8; ++e) b[j][e] = (LT)D[(16 * s + 8 * lh + e) * BNT + b_col + j * 32];
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = LowPrec<PREC>::mfma(a[i], b[j], acc[i][j]);
                 }
             } else {
 #pragma unroll
@@ -1151,7 +1172,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradPara
 template <int BKT, int BNT, int WM, int WN>
 static int launch_wgrad_fast(const WgradParams& q, int S, hipStream_t st) {
     dim3 grid(((q.c.K + BKT - 1) / BKT) * ((q.c.Cout + BNT - 1) / BNT) * S), block(WM * WN * 64);
-    if (g_conv_bf16) hipLaunchKernelGGL((conv_wgrad_fast_kernel<BKT, BNT, WM, WN, true>), grid, block, 0, st, q);
+    if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_wgrad_fast_kernel<BKT, BNT, WM, WN, 1>), grid, block, 0, st, q);
+    else if (g_conv_bf16 == 2) hipLaunchKernelGGL((conv_wgrad_fast_kernel<BKT, BNT, WM, WN, 2>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((conv_wgrad_fast_kernel<BKT, BNT, WM, WN>), grid, block, 0, st, q);
     return MMSEG_CHECK_LAUNCH();
 }
@@ -1216,11 +1238,11 @@ __global__ void wprep_parity_kernel(const float* __restrict__ w, float* __restri
 
 extern "C" {
 
-// Process-wide precision of the fast-path forward / data-gradient convolutions: 0 = fp32 MFMA, 1 = bf16 MFMA with fp32
-// accumulation (BASELINE configs #3/#5).  Returns the previous mode.  Not a per-launch argument: the trainers switch it once.
+// Process-wide precision of the fast-path convolutions (forward, data gradient, weight gradient): 0 = fp32 MFMA, 1 = bf16,
+// 2 = fp16 operands with fp32 accumulation (BASELINE configs #3 / #5).  Returns the previous mode.  Not a per-launch argument: the trainers switch it once.
 int mmseg_set_conv_precision(int mode) {
     const int old = g_conv_bf16;
-    g_conv_bf16 = mode ? 1 : 0;
+    g_conv_bf16 = (mode == 1 || mode == 2) ? mode : 0;
     return old;
 }
 int mmseg_get_conv_precision(void) { return g_conv_bf16; }

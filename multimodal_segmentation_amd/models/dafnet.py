@@ -37,6 +37,7 @@ class DAFNet(MMSDNet):
         self.build_image_discriminator1()
         self.build_image_discriminator2()
         self.build_generators()
+        self.apply_loss_scale()
         try:
             self.load_models()
         except Exception:

@@ -39,7 +39,7 @@ class DiscriminatorModel(nn.Model):
             l = nn.conv(self, 'c%d' % (i + 1), l, stride=s, padding='valid', act='leaky', alpha=0.2)
         return nn.dense(self, 'out', l.reshape(l.shape[0], -1))
 
-    def regulariser_losses(self, accumulate_grad=True):
+    def regulariser_losses(self, accumulate_grad=True, grad_scale=1.0):
         """Sum of the Spectral penalties of the down-sample blocks; their gradient is accumulated into the gradient
         arena when the model is trainable.  -> list of device scalars."""
         names = ['c%d' % (i + 1) for i in range(len(self.strides))]
@@ -49,7 +49,7 @@ class DiscriminatorModel(nn.Model):
             ws_ = [self.params[n + '/kernel'] for n in grp]
             loss, sgn = ops.spectral_reg_multi([w.data for w in ws_], [self.params[n + '/u0'].data for n in grp], 10.0)
             if accumulate_grad and self.trainable:
-                ops.spectral_reg_grad_accumulate([w.data for w in ws_], sgn, [w.grad for w in ws_])
+                ops.spectral_reg_grad_accumulate([w.data for w in ws_], sgn, [w.grad for w in ws_], scale=grad_scale)
             out += [loss[i:i + 1] for i in range(len(grp))]
         return out
 

@@ -38,15 +38,26 @@ class MMSDNet(BaseNet):
         global_rng(conf.seed if hasattr(conf, 'seed') else 10)
 
     def apply_compute_dtype(self):
-        """conf.compute_dtype (build-defined key, default 'fp32'): 'bf16' runs the MFMA products of the fast-path forward /
-        data-gradient convolutions on bf16-rounded operands with fp32 accumulation (BASELINE configs #3 / #5: reduced-
+        """conf.compute_dtype (build-defined key, default 'fp32'): 'bf16' / 'fp16' run the MFMA products of the fast-path
+        convolutions on operands rounded to that type with fp32 accumulation (BASELINE configs #3 / #5: reduced-
         precision compute, fp32 master weights, fp32 gradient all-reduce).  Process-wide switch of the kernel library."""
         ops.set_conv_precision(self.conf.get('compute_dtype', 'fp32'))
+
+    def apply_loss_scale(self):
+        """fp16 compute: static loss scale (conf.loss_scale, default 1024) on every trainer, so that small gradients survive
+        the rounding of the data-gradient operands to fp16; bf16 / fp32 have fp32's exponent range and need none."""
+        scale = float(self.conf.get('loss_scale', 1024.0)) if self.conf.get('compute_dtype', 'fp32') == 'fp16' else 1.0
+        for name in ('supervised_trainer', 'unsupervised_trainer', 'Z_Regressor', 'D_Mask_trainer', 'D_Image1_trainer',
+                     'D_Image2_trainer'):
+            t = getattr(self, name, None)
+            if t is not None:
+                t.loss_scale = scale
 
     def build(self):
         self.apply_compute_dtype()
         self.build_mask_discriminator()
         self.build_generators()
+        self.apply_loss_scale()
         self.load_models()
 
     # ---- checkpoint: one file for the whole supervised trainer (mmsdnet.py:42-60) --------------------------------

@@ -36,6 +36,9 @@ class Trainer(object):
         self.all_models = list(all_models) or self.train_models
         self.device = self.train_models[0].device
         self.last_outputs = None
+        # static loss scale (fp16 compute mode): every seed gradient is multiplied by it, the gradient arenas are divided by it
+        # before the optimiser step; 1.0 = off
+        self.loss_scale = 1.0
 
     # keras API used by the executors ---------------------------------------------------------------------------
     @property
@@ -47,17 +50,18 @@ class Trainer(object):
                                                                    ', '.join(m.name for m in self.train_models)))
 
     def _loss_and_grad(self, spec, pred, target):
+        gs = spec.weight * self.loss_scale            # scale of the returned gradient only; the loss value is unscaled
         if spec.kind == 'dice_bce':
-            return ops.seg_loss(pred, target, self.num_masks, 0.01, spec.weight, class_sum_hook=dp.class_sum_hook(),
+            return ops.seg_loss(pred, target, self.num_masks, 0.01, gs, class_sum_hook=dp.class_sum_hook(),
                                 n_pix_global=pred.numel() // pred.shape[-1] * dp.world_size())
         if spec.kind == 'dice':
-            return ops.seg_loss(pred, target, self.num_masks, 0.0, spec.weight)
+            return ops.seg_loss(pred, target, self.num_masks, 0.0, gs)
         if spec.kind == 'mse':
-            return ops.diff_loss(pred, target, 'mse', spec.weight)
+            return ops.diff_loss(pred, target, 'mse', gs)
         if spec.kind == 'mae':
-            return ops.diff_loss(pred, target, 'mae', spec.weight)
+            return ops.diff_loss(pred, target, 'mae', gs)
         if spec.kind == 'ypred':
-            return ops.diff_loss(pred, 0.0, 'mean', spec.weight)
+            return ops.diff_loss(pred, 0.0, 'mean', gs)
         raise ValueError(spec.kind)
 
     def _prep_target(self, t, pred):
@@ -91,9 +95,12 @@ class Trainer(object):
                 hist.record(spec.name + '_loss', loss)
             torch.autograd.backward(outs, grads)
         for d in self.regularised:
-            for loss in d.regulariser_losses(accumulate_grad=d in self.train_models):
+            for loss in d.regulariser_losses(accumulate_grad=d in self.train_models, grad_scale=self.loss_scale):
                 terms.append((1.0, loss))
         dp.finish(tracker)
+        if self.loss_scale != 1.0:
+            for m in self.train_models:
+                ops.axpby(m.grad_arena, m.grad_arena, 1.0 / self.loss_scale, 0.0, out=m.grad_arena)
         self.optimizer.step(self.train_models)
         hist.record('loss', nn_total(terms))
         self.last_outputs = [o.detach() for o in outs]

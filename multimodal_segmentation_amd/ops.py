@@ -41,12 +41,15 @@ def _c(t):
 # ------------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------------
+_PRECISIONS = ['fp32', 'bf16', 'fp16']
+
+
 def set_conv_precision(mode):
-    """'fp32' (default) or 'bf16': precision of the MFMA products of the fast-path forward / data-gradient convolutions
-    (operands rounded to bf16, fp32 accumulation; tensors in HBM, weight gradients, normalisation, losses and the optimiser
+    """'fp32' (default), 'bf16' or 'fp16': precision of the MFMA products of the fast-path convolutions (operands
+    rounded to the 16-bit type, fp32 accumulation; tensors in HBM, weight gradients, normalisation, losses and the optimiser
     stay fp32).  Returns the previous mode."""
-    old = N.call('mmseg_set_conv_precision', {'fp32': 0, 'bf16': 1}[mode])
-    return 'bf16' if old else 'fp32'
+    old = N.call('mmseg_set_conv_precision', _PRECISIONS.index(mode))
+    return _PRECISIONS[old]
 
 
 def _conv_geometry(H, W, KH, KW, stride, padding):

@@ -52,7 +52,7 @@ _precision = [0]
 
 def set_conv_precision(mode):
     old = _precision[0]
-    _precision[0] = int(bool(mode))
+    _precision[0] = mode if mode in (1, 2) else 0
     return old
 
 

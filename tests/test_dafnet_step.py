@@ -209,7 +209,8 @@ def test_executor_schedule(l_mix, passes, device):
 
 
 @pytest.mark.gpu
-def test_generator_step_bf16_compute_close_to_fp32():
+@pytest.mark.parametrize('mode', ['bf16', 'fp16'])
+def test_generator_step_bf16_compute_close_to_fp32(mode):
     """conf.compute_dtype = 'bf16' (BASELINE configs #3 / #5: bf16 MFMA operands, fp32 accumulation / storage / weight
     gradients): every loss term of a generator step stays within 2e-2 of the fp32 step on the same weights and draws, and
     the process-wide precision switch is restored by the next fp32 build."""
@@ -219,7 +220,7 @@ def test_generator_step_bf16_compute_close_to_fp32():
     d = Hh.make_step_data(B, H, H)
     res = {}
     try:
-        for dt in ('fp32', 'bf16'):
+        for dt in ('fp32', mode):
             conf = Hh.make_conf(dafnet_config_chaos, H, compute_dtype=dt)
             from multimodal_segmentation_amd.utils import rng as R
             model = DAFNet(conf)
@@ -238,11 +239,35 @@ def test_generator_step_bf16_compute_close_to_fp32():
             if dt == 'fp32':
                 teacher = [model.last_factors['s1'].detach().clone(), model.last_factors['s2'].detach().clone()]
             res[dt] = {k: h.history[k][0] for k in h.history.keys()}
-        assert P.set_conv_precision('fp32') == 'bf16'            # the bf16 build had switched the library
+        assert P.set_conv_precision('fp32') == mode              # the reduced-precision build had switched the library
+        assert model.supervised_trainer.loss_scale == (1024.0 if mode == 'fp16' else 1.0)
     finally:
         P.set_conv_precision('fp32')
     for k, v in res['fp32'].items():
         # the discriminators' heads sum 373k bf16-rounded features of a randomly initialised network: looser there
         tol = 5e-2 if k in ('loss', 'D_Mask_loss', 'D_Image1_loss', 'D_Image2_loss') else 2e-2
-        assert abs(res['bf16'][k] - v) <= tol * max(1.0, abs(v)), (k, v, res['bf16'][k])
-    assert any(abs(res['bf16'][k] - v) > 1e-6 for k, v in res['fp32'].items())      # and bf16 really ran
+        assert abs(res[mode][k] - v) <= tol * max(1.0, abs(v)), (k, v, res[mode][k])
+    assert any(abs(res[mode][k] - v) > 1e-6 for k, v in res['fp32'].items())      # and the 16-bit path really ran
+
+
+def test_loss_scale_is_transparent(device):
+    """The static loss scale of the fp16 mode multiplies every seed gradient (and the regulariser gradients) and is divided
+    out of the gradient arenas before Adam: in exact arithmetic the step does not change.  Checked on the discriminator
+    trainer (outputs + Spectral regularisers) in fp32."""
+    B, H = 2, 64
+    conf, model = _build('film', H, device)
+    d = Hh.make_step_data(B, H, H)
+    w0 = model.D_Mask.get_weights()
+    out = {}
+    for scale in (1.0, 256.0):
+        model.D_Mask.set_weights(w0)
+        tr = model._d_trainer(model.D_Mask, 'D_Mask_trainer_%d' % scale, conf.d_mask_params.lr)
+        tr.loss_scale = scale
+        h = tr.fit([d['dm_m1'], d['dm_m2']], [1.0, 0.0])
+        out[scale] = (h.history['loss'][0], model.D_Mask.grad_arena.detach().cpu().numpy().copy(),
+                      np.concatenate([w.ravel() for w in model.D_Mask.get_weights()]))
+    assert abs(out[1.0][0] - out[256.0][0]) <= 1e-6 * abs(out[1.0][0])                   # reported loss is unscaled
+    g1, g2 = out[1.0][1], out[256.0][1]
+    assert np.abs(g1).max() > 0 and np.abs(g1 - g2).max() <= 1e-5 * np.abs(g1).max()
+    assert np.abs(out[1.0][2] - out[256.0][2]).max() <= 1e-7
+    model.D_Mask.set_weights(w0)
