@@ -95,10 +95,14 @@ class Experiment(object):
             json.dump(dict(conf.items()), f, default=_jsonable)
 
     def init_logging(self, conf):
+        """<folder>/logfile.log at DEBUG level + the console (experiment.py:21-29).  Handlers are attached explicitly, so the
+        log file also appears when the embedding process has configured the root logger already."""
         os.makedirs(conf.folder, exist_ok=True)
-        logging.basicConfig(filename=os.path.join(conf.folder, 'logfile.log'), level=logging.DEBUG,
-                            format='%(asctime)s %(message)s')
         root = logging.getLogger()
+        root.setLevel(logging.DEBUG)
+        fh = logging.FileHandler(os.path.join(conf.folder, 'logfile.log'))
+        fh.setFormatter(logging.Formatter('%(asctime)s %(message)s'))
+        root.addHandler(fh)
         root.addHandler(logging.StreamHandler())
         self.log = root
         root.debug(conf.items())
