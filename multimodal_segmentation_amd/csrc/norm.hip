@@ -248,13 +248,24 @@ __global__ void in_final_kernel(const float* __restrict__ part, const float* __r
 // y = act( (x - mean)*rstd * (1 + gamma) + beta ); gamma/beta nullptr -> plain normalisation. act_alpha<0: no activation
 __global__ void in_apply_kernel(const float* __restrict__ x, const float* __restrict__ stat, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float* __restrict__ y, long per_sample, long n, float act_alpha) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int b = i / per_sample;
-        float v = (x[i] - stat[2 * b]) * stat[2 * b + 1];
-        if (gamma) v = v * (1.f + gamma[i]) + beta[i];
-        if (act_alpha >= 0.f) v = v >= 0.f ? v : v * act_alpha;
-        y[i] = v;
+    // grid (chunks, B): one sample per blockIdx.y, 16-byte accesses (per_sample = H*W*C is a multiple of 4)
+    const int b = blockIdx.y;
+    const float mu = stat[2 * b], rs = stat[2 * b + 1];
+    const size_t off4 = (size_t)b * (per_sample >> 2);
+    const f32x4* X = reinterpret_cast<const f32x4*>(x) + off4;
+    const f32x4* G = gamma ? reinterpret_cast<const f32x4*>(gamma) + off4 : nullptr;
+    const f32x4* Bt = gamma ? reinterpret_cast<const f32x4*>(beta) + off4 : nullptr;
+    f32x4* Y = reinterpret_cast<f32x4*>(y) + off4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (per_sample >> 2); i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = (X[i] - mu) * rs;
+        if (G) v = v * (G[i] + 1.f) + Bt[i];
+        if (act_alpha >= 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * act_alpha;
+        }
+        Y[i] = v;
     }
+    (void)n;
 }
 // backward of the fused op.  With xn = (x-mean)*rstd, u = xn*(1+gamma)+beta, y = leaky(u):
 //   g = dy*leaky'(u); dgamma = g*xn; dbeta = g; dxn = g*(1+gamma)
@@ -298,17 +309,26 @@ __global__ void in_bwd_partial_kernel(const float* __restrict__ dy, const float*
 //     dx_j = rs*(dxn_j - S1/N) - xn_j * S2 / (N * sd)
 __global__ void in_bwd_apply_kernel(const float* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stat,
                                     const float* __restrict__ part, float* __restrict__ dx, long per_sample, long n, int nchunk, float eps) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int b = i / per_sample;
-        float s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < nchunk; ++k) { s1 += part[((size_t)b * nchunk + k) * 2]; s2 += part[((size_t)b * nchunk + k) * 2 + 1]; }
-        const float mu = stat[2 * b], rs = stat[2 * b + 1];
-        const float sd = 1.f / rs - eps;
-        const float invN = 1.f / (float)per_sample;
-        const float xn = (x[i] - mu) * rs;
-        const float t = sd > 0.f ? xn * s2 * invN / sd : 0.f;
-        dx[i] = rs * (dxn[i] - s1 * invN) - t;
+    // grid (chunks, B).  The per-sample sums are reduced ONCE per block (they used to be re-summed by every element).
+    __shared__ float red[17];
+    const int b = blockIdx.y;
+    float p1 = 0.f, p2 = 0.f;
+    for (int k = threadIdx.x; k < nchunk; k += blockDim.x) { p1 += part[((size_t)b * nchunk + k) * 2]; p2 += part[((size_t)b * nchunk + k) * 2 + 1]; }
+    const float s1 = block_sum(p1, red);
+    const float s2 = block_sum(p2, red);
+    const float mu = stat[2 * b], rs = stat[2 * b + 1];
+    const float sd = 1.f / rs - eps;
+    const float invN = 1.f / (float)per_sample;
+    const float c1 = s1 * invN, c2 = sd > 0.f ? s2 * invN / sd : 0.f;
+    const size_t off4 = (size_t)b * (per_sample >> 2);
+    const f32x4* X = reinterpret_cast<const f32x4*>(x) + off4;
+    const f32x4* D = reinterpret_cast<const f32x4*>(dxn) + off4;
+    f32x4* O = reinterpret_cast<f32x4*>(dx) + off4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (per_sample >> 2); i += (long)gridDim.x * blockDim.x) {
+        const f32x4 xn = (X[i] - mu) * rs;
+        O[i] = (D[i] - c1) * rs - xn * c2;
     }
+    (void)n;
 }
 
 // row blocks of the float4 fast path: ~1024 blocks in total, at most 512 row blocks, at least 64 rows per block
@@ -391,6 +411,13 @@ int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* g
 }
 
 #define IN_CHUNKS 64
+// blocks per sample of the element-wise InstanceNorm passes: ~4 float4 per thread, at most 512
+static inline int in_apply_chunks(long per_sample) {
+    long c = (per_sample / 4 + 1023) / 1024;
+    if (c > 512) c = 512;
+    if (c < 1) c = 1;
+    return (int)c;
+}
 int mmseg_in_workspace_floats(int B) { return B * IN_CHUNKS * 2; }
 // stat: [B][2] output (mean, 1/(std+eps)); y = act((x-mean)*rstd*(1+gamma)+beta)
 int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float* ws, int B,
@@ -399,7 +426,8 @@ int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* be
     hipLaunchKernelGGL(in_partial_kernel, dim3(IN_CHUNKS, B), dim3(256), 0, st, x, ws, per_sample, IN_CHUNKS);
     hipLaunchKernelGGL(in_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const float*)ws, x, stat, per_sample, IN_CHUNKS, B, eps);
     const long n = (long)B * per_sample;
-    hipLaunchKernelGGL(in_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, (const float*)stat, gamma, beta, y, per_sample, n, act_alpha);
+    if (per_sample & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(in_apply_kernel, dim3(in_apply_chunks(per_sample), B), dim3(256), 0, st, x, (const float*)stat, gamma, beta, y, per_sample, n, act_alpha);
     return MMSEG_CHECK_LAUNCH();
 }
 // dxn: scratch [B*per_sample]; dgamma/dbeta may be nullptr when gamma is nullptr
@@ -410,7 +438,8 @@ int mmseg_instnorm_spade_bwd(const float* dy, const float* x, const float* stat,
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(IN_CHUNKS, B), dim3(256), 0, st, dy, x, stat, gamma, beta, dgamma, dbeta, dxn, ws,
                        per_sample, IN_CHUNKS, act_alpha);
     const long n = (long)B * per_sample;
-    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, (const float*)dxn, x, stat, (const float*)ws, dx, per_sample, n, IN_CHUNKS, eps);
+    if (per_sample & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(in_apply_chunks(per_sample), B), dim3(256), 0, st, (const float*)dxn, x, stat, (const float*)ws, dx, per_sample, n, IN_CHUNKS, eps);
     return MMSEG_CHECK_LAUNCH();
 }
 
