@@ -119,18 +119,24 @@ def test_mmsdnet_train_epoch_then_test():
 
 
 @pytest.mark.gpu
-def test_training_learns_on_the_synthetic_split():
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
+def test_training_learns_on_the_synthetic_split(dtype):
     """six short epochs (84 iterations, lr 1e-4, augmentation on): the supervised segmentation loss falls by > 10 % and the
     validation Dice loss of the SWA clones improves"""
     nn.set_default_device('cuda:0')
     from multimodal_segmentation_amd.models.dafnet import DAFNet
     from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
-    conf = Hh.make_conf(dafnet_config_chaos, 64, batch_size=4, epochs=6, slices_per_volume=4, test_dataset='chaos')
-    conf.folder = '/tmp/mmseg_test_learns'
+    conf = Hh.make_conf(dafnet_config_chaos, 64, batch_size=4, epochs=6, slices_per_volume=4, test_dataset='chaos',
+                        compute_dtype=dtype)
+    conf.folder = '/tmp/mmseg_test_learns_' + dtype
     shutil.rmtree(conf.folder, ignore_errors=True)
     model = DAFNet(conf)
     model.build()
-    total = DAFNetExecutor(conf, model).train()
+    try:
+        total = DAFNetExecutor(conf, model).train()
+    finally:
+        from multimodal_segmentation_amd import ops as P
+        P.set_conv_precision('fp32')
     seg = total['supervised_Mask']
     assert seg[-1] < 0.9 * seg[0], seg
     assert total['val_loss'][-1] < total['val_loss'][0], total['val_loss']
