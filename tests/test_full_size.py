@@ -135,3 +135,35 @@ def test_full_size_iteration_is_finite_and_learns_on_a_fixed_batch():
     assert rec[-1] < rec[0], rec
     m = model.Segmentor.predict(model.Encoders_Anatomy[0].predict(d['x1']))
     assert m.shape == (B, H, H, 5) and abs(float(m.sum(-1).mean()) - 1) < 1e-4
+
+
+def test_bitwise_reproducibility_of_a_discriminator_step_and_of_the_convolutions():
+    """Every reduction runs in a fixed order (slabs, two-stage column sums, no float atomics outside the TPS resampler's
+    scatter): the same step from the same state is bit-identical run to run."""
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    x, w = rnd(B, 128, 128, 128, seed=31).to(DEV), (rnd(3, 3, 128, 128, seed=32) * 0.03).to(DEV)
+    cot = rnd(B, 128, 128, 128, seed=33).to(DEV)
+    runs = []
+    for _ in range(2):
+        xd = x.clone().requires_grad_(True)
+        wg = torch.zeros_like(w)
+        y = P.conv2d(xd, w, None, wgrad=wg, anchor=nn.anchor(xd.device))
+        y.backward(cot)
+        runs.append((y.detach().clone(), xd.grad.clone(), wg.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    conf = Hh.make_conf(dafnet_config_chaos, 128, batch_size=4)
+    model = DAFNet(conf)
+    model.build()
+    d = Hh.make_step_data(4, 128, 128, seed=3)
+    w0 = model.D_Mask.get_weights()
+    outs = []
+    for _ in range(2):
+        model.D_Mask.set_weights(w0)
+        tr = model._d_trainer(model.D_Mask, 'D_Mask_trainer_rep', conf.d_mask_params.lr)
+        tr.fit([d['dm_m1'], d['dm_m2']], [1.0, 0.0])
+        outs.append((model.D_Mask.grad_arena.clone(), model.D_Mask.arena.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
