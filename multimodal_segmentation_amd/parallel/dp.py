@@ -116,7 +116,8 @@ def broadcast_models(models, src=0):
     if not enabled():
         return
     for m in models:
-        dist.broadcast(m.arena, src=src)
-        dist.broadcast(m.state_arena, src=src)
+        for t in (m.arena, m.state_arena):
+            if t is not None and t.numel() > 0:          # components without non-trainable state have an empty arena
+                dist.broadcast(t, src=src)
     from .. import ops
     ops.bump_weight_version()
