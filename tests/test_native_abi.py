@@ -44,3 +44,22 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, '_lib', None)
     with pytest.raises(_native.NativeLibraryError):
         _native.load()
+
+
+def test_header_is_plain_c_and_query_entry_points_work_from_c(tmp_path):
+    """include/mmseg_hip.h compiles with a C compiler (-std=c99 -pedantic) and a C program linked against the shared
+    library can call every entry point that launches nothing."""
+    import shutil
+    import subprocess
+    from multimodal_segmentation_amd import _native
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    _native.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'c_abi_check')
+    libdir = os.path.dirname(_native.LIB_PATH)
+    subprocess.check_call(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(root, 'include'),
+                           os.path.join(root, 'tests', 'c_abi_check.c'), '-o', exe, '-L', libdir, '-l:libmmseg_hip.so',
+                           '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib', '-L/opt/rocm/lib', '-lamdhip64'])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert out.returncode == 0 and b'C ABI OK' in out.stdout, out.stdout
