@@ -182,3 +182,74 @@ def test_two_independent_restatements_of_conv_and_maxpool():
             assert np.abs(y2[0, i, j] - np.einsum('hwc,hwco->o', x[0, 2 * i:2 * i + 3, 2 * j:2 * j + 3], w)).max() < 1e-10
     mp = O.maxpool2(torch.tensor(x[:, :4, :6])).numpy()
     assert np.allclose(mp[0, 1, 2], x[0, 2:4, 4:6].max((0, 1)))
+
+
+def test_perbatch_cross_entropy_hand_value_and_second_restatement():
+    """costs.py:88-108 as CALLED at costs.py:142 (labels and prediction swapped): class weights from the prediction over the
+    whole batch, softmax + log applied to the labels.  One hand-computed case + explicit numpy loops on random data."""
+    # B = 1, one pixel, two classes: label one-hot [1, 0], prediction [0.75, 0.25]
+    t = torch.tensor([1.0, 0.0], dtype=torch.float64).reshape(1, 1, 1, 2)
+    p = torch.tensor([0.75, 0.25], dtype=torch.float64).reshape(1, 1, 1, 2)
+    sm = np.exp([1.0, 0.0]) / np.exp([1.0, 0.0]).sum()                      # softmax of the LABELS
+    w = 1.0 / (np.array([0.75, 0.25]) + 1e-12)                               # n_tot / (n_c + eps), n from the PREDICTION
+    expect = -np.sum(np.array([0.75, 0.25]) * np.log(sm + 1e-12) * w)
+    got = O.weighted_cross_entropy_perbatch(t, p)                            # (y_pred := labels, y_true := prediction)
+    assert abs(float(got[0]) - expect) < 1e-12 and abs(expect - (-(math.log(sm[0]) + math.log(sm[1])))) < 1e-9
+    rs = np.random.RandomState(0)
+    B, H, W, C = 3, 4, 5, 5
+    lab = np.eye(C)[rs.randint(0, C, (B, H, W))]
+    prd = rs.rand(B, H, W, C); prd /= prd.sum(-1, keepdims=True)
+    n = prd.sum((0, 1, 2)); wts = n.sum() / (n + 1e-12)
+    ref = np.zeros(B)
+    for b in range(B):
+        acc = 0.0
+        for i in range(H):
+            for j in range(W):
+                e = np.exp(lab[b, i, j] - lab[b, i, j].max()); s = e / e.sum()
+                acc += -sum(prd[b, i, j, c] * math.log(s[c] + 1e-12) * wts[c] for c in range(C))
+        ref[b] = acc / (H * W)
+    got = O.weighted_cross_entropy_perbatch(torch.tensor(lab), torch.tensor(prd)).numpy()
+    assert np.abs(got - ref).max() < 1e-10
+    # combined per-sample loss = per-sample Dice over the first 4 channels + 0.01 * the above
+    dice = np.array([1 - (2 * (lab[b, ..., :4] * prd[b, ..., :4]).sum() + 1e-12) /
+                     (lab[b, ..., :4].sum() + prd[b, ..., :4].sum() + 1e-12) for b in range(B)])
+    got = O.combined_dice_bce_perbatch(torch.tensor(lab), torch.tensor(prd), 4).numpy()
+    assert np.abs(got - (dice + 0.01 * ref)).max() < 1e-10
+
+
+def test_pair_dice_balancer_and_single_input_mae_hand_values():
+    a = torch.zeros(2, 2, 2, 1, dtype=torch.float64); b = torch.zeros(2, 2, 2, 1, dtype=torch.float64)
+    a[0, 0, 0, 0] = 1; a[0, 1, 1, 0] = 1; b[0, 0, 0, 0] = 1                  # sample 0: |a| = 2, |b| = 1, overlap 1 -> 2/3
+    d = O.pair_dice(a, b)                                                      # sample 1: both empty -> eps / eps = 1
+    assert d.shape == (2, 1) and abs(float(d[0, 0]) - 2.0 / 3.0) < 1e-12 and abs(float(d[1, 0]) - 1.0) < 1e-12
+    x = torch.tensor([[1.0, -1.0], [0.5, 0.0]], dtype=torch.float64).reshape(1, 2, 2, 1)
+    y = torch.zeros(1, 2, 2, 1, dtype=torch.float64)
+    assert O.mae_single_input(x, y).shape == (1, 1) and abs(float(O.mae_single_input(x, y)) - 0.625) < 1e-12
+    # Balancer: equal overlaps -> equal dense inputs -> softmax of the beta layer's bias only
+    from oracle import models as OM
+    P = {'BAL/d0/kernel': torch.zeros(3, 5, dtype=torch.float64), 'BAL/d0/bias': torch.zeros(5, dtype=torch.float64),
+         'BAL/beta/kernel': torch.ones(5, 3, dtype=torch.float64), 'BAL/beta/bias': torch.tensor([0.0, math.log(2.0), 0.0], dtype=torch.float64)}
+    w = OM.balancer(a, b, b, b, P)
+    assert np.allclose(w.numpy(), [[0.25, 0.5, 0.25]] * 2, atol=1e-12)
+
+
+def test_keras_flow_stream_reseeds_the_global_rng():
+    """NumpyArrayIterator(shuffle=True, seed=s): batch k is drawn after np.random.seed(s + k); the first batch of a pass
+    also draws the permutation; one uniform(-20, 20) per sample follows.  Restated twice (product stream, oracle iterator)."""
+    from multimodal_segmentation_amd.utils.augment import KerasFlowStream
+    from oracle.augment import KerasFlowOracle
+    s = KerasFlowStream(5, 2, 10, 20.0)
+    rows0, th0 = s.next()
+    np.random.seed(10); perm = np.random.permutation(5); u = [np.deg2rad(np.random.uniform(-20, 20)) for _ in range(2)]
+    assert rows0.tolist() == perm[:2].tolist() and np.allclose(th0, u)
+    rows1, th1 = s.next()
+    np.random.seed(11); u1 = [np.deg2rad(np.random.uniform(-20, 20)) for _ in range(2)]      # no new permutation mid-pass
+    assert rows1.tolist() == perm[2:4].tolist() and np.allclose(th1, u1)
+    rows2, _ = s.next()
+    assert rows2.tolist() == perm[4:].tolist()                                               # short last batch
+    rows3, _ = s.next()
+    np.random.seed(13); perm2 = np.random.permutation(5)
+    assert rows3.tolist() == perm2[:2].tolist()                                              # new pass, new permutation
+    x = np.arange(5 * 4 * 4, dtype=np.float32).reshape(5, 4, 4, 1)
+    o = KerasFlowOracle(x, 2, 10, rotation_range=0.0)
+    assert np.array_equal(next(o)[:, 0, 0, 0], x[perm[:2], 0, 0, 0])
