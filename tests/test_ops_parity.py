@@ -109,6 +109,9 @@ CONV_CASES = [
     (2, 33, 31, 1, 0, 64, 4, 2, 'valid', 'leaky', False),      # D_Image first layer, odd sizes: direct small-Cin data gradient
     (2, 33, 33, 16, 0, 32, 3, 2, 'valid', 'leaky', False),     # modality-encoder layer: batched parity classes with 2x1 / 1x1 taps
     (2, 31, 31, 64, 0, 128, 4, 2, 'valid', 'leaky', False),    # odd input: parity classes of different sizes in one launch
+    (2, 18, 22, 8, 0, 64, 3, 1, 'same', 'relu', False),        # segmentor c0: its data gradient is a 64 -> 8 3x3 launch (N = 8)
+    (3, 17, 19, 64, 0, 8, 3, 1, 'same', 'leaky', False),       # N = 8 on the 32-wide fast tile, odd sizes
+    (3, 17, 19, 8, 0, 5, 1, 1, 'same', None, False),           # tiny 1x1 head through the generic kernel
 ]
 
 
