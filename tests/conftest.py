@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The oracle runs on torch-CPU.  A GPU box exposes far more logical CPUs (256) than the share a job may use (16 per GPU):
+    # torch's default of one thread per logical CPU then oversubscribes the share and the oracle crawls.
+    import torch
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(n, 16)))
 
 
 @pytest.fixture
