@@ -14,11 +14,15 @@ cfg['batch_size'] = B; cfg['n_pairs'] = 1; cfg['folder'] = '/tmp/mmseg_leak'
 conf = EasyDict(cfg); model = DAFNet(conf); model.build()
 ex = DAFNetExecutor(conf, model); ex.keep_losses_on_device = True; ex.init_train_data(slices_per_volume=4)
 losses = {n: [] for n in ex.get_loss_names()}
-for i in range(121):
+N_IT = int(os.environ.get('ITERS', 121))
+t0 = time.time()
+for i in range(N_IT):
     ex.train_batch(losses)
-    if i in (5, 20, 60, 120):
+    if i in (5, 20, 60, 120) or i == N_IT - 1:
         torch.cuda.synchronize()
         print(i, 'allocated %.2f GB reserved %.2f GB max %.2f GB; caches: wprep %d bnfold %d ws %d' % (
             torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9, torch.cuda.max_memory_allocated() / 1e9,
             len(ops._wprep_cache), len(ops._bnfold_cache), len(ops._workspaces)), flush=True)
+    if i == N_IT - 1:
+        print('last losses:', {k: round(float(v[-1].item() if hasattr(v[-1], 'item') else v[-1]), 4) for k, v in losses.items() if v}, ' %.1f ms/iter overall' % (1e3 * (time.time() - t0) / N_IT))
     for k in losses: losses[k].clear()
