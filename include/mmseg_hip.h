@@ -17,7 +17,8 @@
  *   - the return value is a hipError_t as int (0 = hipSuccess); invalid geometry returns hipErrorInvalidValue
  *     without launching anything;
  *   - reductions are two-stage and run in a fixed order: results are bitwise reproducible run to run
- *     (exception: mmseg_tps_warp_bwd's d_vol uses float atomics).
+  *     (the one scatter, mmseg_tps_warp_bwd's d_vol, accumulates in 64-bit fixed point with integer atomics, which is
+ *     order-independent as well).
  */
 #ifndef MMSEG_HIP_H
 #define MMSEG_HIP_H
@@ -157,8 +158,11 @@ int mmseg_dense_wgrad(const float* x, const float* dy, float* dw, int R, int K, 
 int mmseg_tps_workspace_floats(int B);
 int mmseg_tps_warp_fwd(const float* vol, const float* theta, const float* Mb, float* out, float* loc, int B, int H, int W, int C,
                        void* stream);
+long mmseg_tps_scatter_workspace_floats(int B, int H, int W, int C);
+/* acc: mmseg_tps_scatter_workspace_floats floats (8-byte aligned) -- 64-bit fixed-point accumulators of the d_vol scatter, which
+ * make it independent of the order of the atomics (bitwise reproducible) */
 int mmseg_tps_warp_bwd(const float* vol, const float* loc, const float* Mb, const float* dout, float* dvol, float* dtheta, float* dloc,
-                       float* ws, int B, int H, int W, int C, void* stream);
+                       float* ws, float* acc, int B, int H, int W, int C, void* stream);
 
 /* ---- batch gather + affine (rotation) augmentation (csrc/augment.hip): keras ImageDataGenerator(rotation_range=20)
  *      .flow of model_executors/base_executor.py:37-78,103-110 = scipy affine_transform(order=1, mode='nearest') ---- */

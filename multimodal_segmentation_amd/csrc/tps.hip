@@ -62,10 +62,13 @@ __global__ void tps_warp_fwd_kernel(const float* __restrict__ vol, const float* 
     for (int c = 0; c < C; ++c) o[c] = acc[c];
 }
 
-// backward: d_vol via float atomics (scatter), d_loc[b,p,2] = (dL/dx, dL/dy) in pixel units
+// backward: d_vol is a scatter (4 taps per output pixel).  The contributions are accumulated with 64-bit INTEGER atomics in
+// fixed point (2^-36 resolution, range +-1.3e8): integer addition is associative, so the result does not depend on the order
+// in which the atomics land and the whole training step stays bitwise reproducible.  d_loc[b,p,2] = (dL/dx, dL/dy) in pixels.
+#define TPS_FX_SCALE 68719476736.0      /* 2^36 */
 template <int C>
 __global__ void tps_warp_bwd_kernel(const float* __restrict__ vol, const float* __restrict__ loc, const float* __restrict__ dout,
-                                    float* __restrict__ dvol, float* __restrict__ dloc, int H, int W) {
+                                    unsigned long long* __restrict__ dvol, float* __restrict__ dloc, int H, int W) {
     const int b = blockIdx.y;
     const int HW = H * W;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,7 +78,7 @@ __global__ void tps_warp_bwd_kernel(const float* __restrict__ vol, const float* 
     const float ax = x - fxf, ay = y - fyf;
     const int fx = (int)fminf(fmaxf(fxf, -2.f), (float)W), fy = (int)fminf(fmaxf(fyf, -2.f), (float)H);
     const float* vb = vol + (size_t)b * HW * C;
-    float* dvb = dvol ? dvol + (size_t)b * HW * C : nullptr;
+    unsigned long long* dvb = dvol ? dvol + (size_t)b * HW * C : nullptr;
     float g[C];
     const float* go = dout + ((size_t)b * HW + p) * C;
 #pragma unroll
@@ -92,13 +95,22 @@ __global__ void tps_warp_bwd_kernel(const float* __restrict__ vol, const float* 
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 dot += g[c] * src[c];
-                if (dvb) atomicAdd(dvb + ((size_t)yi * W + xi) * C + c, g[c] * wx * wy);
+                if (dvb) atomicAdd(dvb + ((size_t)yi * W + xi) * C + c,
+                                   (unsigned long long)__double2ll_rn((double)(g[c] * wx * wy) * TPS_FX_SCALE));
             }
             gx += dot * sx * wy;
             gy += dot * sy * wx;
         }
     }
     if (dloc) { dloc[((size_t)b * HW + p) * 2] = gx; dloc[((size_t)b * HW + p) * 2 + 1] = gy; }
+}
+
+__global__ void tps_fx_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (float)((double)acc[i] * (1.0 / TPS_FX_SCALE));
+}
+__global__ void tps_zero_kernel(unsigned long long* __restrict__ acc, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) acc[i] = 0ull;
 }
 
 // part[chunk][b][j][2]: dtheta[b][j][0] (row offset) = sum_p Mb[p][j] * dloc_y * (H-1); [1] (col) uses dloc_x * (W-1)
@@ -137,13 +149,21 @@ int mmseg_tps_warp_fwd(const float* vol, const float* theta, const float* Mb, fl
     hipLaunchKernelGGL(tps_warp_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, vol, theta, Mb, out, loc, H, W);
     return MMSEG_CHECK_LAUNCH();
 }
-// dvol must be zero-filled by the caller (scatter-add); dvol or dtheta may be nullptr to skip that gradient
+// floats of `acc` scratch for the deterministic scatter of d_vol: one 64-bit accumulator per element
+long mmseg_tps_scatter_workspace_floats(int B, int H, int W, int C) { return 2L * B * H * W * C; }
+// dvol or dtheta may be nullptr to skip that gradient; acc: mmseg_tps_scatter_workspace_floats floats, 8-byte aligned
+// (needed only when dvol != nullptr; zeroed here)
 int mmseg_tps_warp_bwd(const float* vol, const float* loc, const float* Mb, const float* dout, float* dvol, float* dtheta, float* dloc,
-                       float* ws, int B, int H, int W, int C, void* stream) {
+                       float* ws, float* acc, int B, int H, int W, int C, void* stream) {
     if (C != 8) return (int)hipErrorInvalidValue;
+    if (dvol && (acc == nullptr || ((uintptr_t)acc & 7))) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((H * W + 255) / 256, B);
-    hipLaunchKernelGGL(tps_warp_bwd_kernel<8>, grid, dim3(256), 0, st, vol, loc, dout, dvol, dtheta ? dloc : (float*)nullptr, H, W);
+    const long n = (long)B * H * W * C;
+    unsigned long long* acc64 = dvol ? reinterpret_cast<unsigned long long*>(acc) : nullptr;
+    if (dvol) hipLaunchKernelGGL(tps_zero_kernel, dim3(2048), dim3(256), 0, st, acc64, n);
+    hipLaunchKernelGGL(tps_warp_bwd_kernel<8>, grid, dim3(256), 0, st, vol, loc, dout, acc64, dtheta ? dloc : (float*)nullptr, H, W);
+    if (dvol) hipLaunchKernelGGL(tps_fx_to_float_kernel, dim3(2048), dim3(256), 0, st, (const long long*)acc64, dvol, n);
     if (dtheta) {
         const int per = (H * W + TPS_CHUNKS - 1) / TPS_CHUNKS;
         const int ncombo = B * TPS_NCP * 2;

@@ -566,16 +566,17 @@ class _TpsWarp(torch.autograd.Function):
         B, H, W, C = vol.shape
         dout = _c(dout)
         dvol = dtheta = None
+        acc = None
         if ctx.needs_input_grad[0]:
             dvol = _new(vol.shape, vol)
-            N.call('mmseg_fill', dvol, dvol.numel(), 0.0)
+            acc = _ws('tps_acc', N.call('mmseg_tps_scatter_workspace_floats', B, H, W, C), vol.device)
         dloc = None
         ws = None
         if ctx.needs_input_grad[1]:
             dtheta = _new(ctx.theta_shape, vol)
             dloc = _ws('tps_dloc', B * H * W * 2, vol.device)
             ws = _ws('tps', N.call('mmseg_tps_workspace_floats', B), vol.device)
-        N.call('mmseg_tps_warp_bwd', vol, loc, Mb, dout, dvol, dtheta, dloc, ws, B, H, W, C)
+        N.call('mmseg_tps_warp_bwd', vol, loc, Mb, dout, dvol, dtheta, dloc, ws, acc, B, H, W, C)
         return dvol, dtheta, None
 
 

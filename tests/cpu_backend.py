@@ -383,14 +383,18 @@ def tps_warp_fwd(vol, theta, Mb, out, loc, B, H, W, C):
     out.copy_(O.resampler(vol.reshape(B, H, W, C), l).reshape(out.shape)); return 0
 
 
-def tps_warp_bwd(vol, loc, Mb, dout, dvol, dtheta, dloc, ws, B, H, W, C):
+def tps_scatter_workspace_floats(B, H, W, C):
+    return 2
+
+
+def tps_warp_bwd(vol, loc, Mb, dout, dvol, dtheta, dloc, ws, acc, B, H, W, C):
     with torch.enable_grad():
         v = vol.detach().clone().reshape(B, H, W, C).requires_grad_(True)
         l = loc.detach().clone().reshape(B, H * W, 2).requires_grad_(True)
         o = O.resampler(v, l)
         gv, gl = torch.autograd.grad(o, [v, l], dout.reshape(o.shape))
     if dvol is not None:
-        dvol.add_(gv.reshape(dvol.shape))
+        dvol.copy_(gv.reshape(dvol.shape))
     if dtheta is not None:
         glr = torch.flip(gl * torch.tensor([W - 1, H - 1], dtype=gl.dtype), dims=[-1])   # -> (row, col) normalised
         dtheta.copy_(torch.einsum('pj,bpk->bjk', Mb, glr).reshape(dtheta.shape))

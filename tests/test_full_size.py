@@ -138,8 +138,9 @@ def test_full_size_iteration_is_finite_and_learns_on_a_fixed_batch():
 
 
 def test_bitwise_reproducibility_of_a_discriminator_step_and_of_the_convolutions():
-    """Every reduction runs in a fixed order (slabs, two-stage column sums, no float atomics outside the TPS resampler's
-    scatter): the same step from the same state is bit-identical run to run."""
+    """Every reduction runs in a fixed order (slabs, two-stage column sums) and the one scatter -- the TPS resampler's data
+    gradient -- accumulates in 64-bit fixed point with integer atomics: the same step from the same state is bit-identical
+    run to run, the whole generator step included."""
     from multimodal_segmentation_amd.configuration import dafnet_config_chaos
     from multimodal_segmentation_amd.models.dafnet import DAFNet
     from tests import helpers as Hh
@@ -167,3 +168,20 @@ def test_bitwise_reproducibility_of_a_discriminator_step_and_of_the_convolutions
         tr.fit([d['dm_m1'], d['dm_m2']], [1.0, 0.0])
         outs.append((model.D_Mask.grad_arena.clone(), model.D_Mask.arena.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # a whole generator step (encoders, fuser incl. the TPS scatter, segmentor, decoder, frozen discriminators, Adam)
+    gens = model._generator_models()
+    g0 = [m.get_weights() for m in gens]
+    tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [1.0] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [1.0] * 4 + [0.0] * 2 + [d['z1'], d['z2']]
+    th = model.Anatomy_Fuser.params['theta/kernel']
+    th.data.copy_(((rnd(*th.shape, seed=41)) * 0.002).to(DEV))           # a non-trivial warp, so that the scatter really scatters
+    g0 = [m.get_weights() for m in gens]
+    steps = []
+    for _ in range(2):
+        for m, w in zip(gens, g0):
+            m.set_weights(w)
+        tr = model.supervised_trainer
+        tr.optimizer = nn.Adam(conf.lr)
+        tr.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']])
+        steps.append([m.grad_arena.clone() for m in gens] + [m.arena.clone() for m in gens])
+    for a, b in zip(*steps):
+        assert torch.equal(a, b)

@@ -4,7 +4,10 @@ identical batches with identical random draws (no teacher forcing), then both ar
 split.  The Rounding layer makes the two trajectories diverge pixel by pixel, so this is a statistical statement, the one the
 north_star asks for: |Dice_product - Dice_oracle| on a fixed synthetic split.
 
-    python tools/dice_parity.py [iterations=60] [size=64] [batch=4] [lr=1e-3]
+    python tools/dice_parity.py [iterations=60] [size=64] [batch=4] [lr=1e-3] [both|product|oracle] [eval_every=10]
+
+`product` / `oracle` run one side only (same seeds, hence the same initial weights, batches and draws): the oracle side needs
+no GPU and can run for hours elsewhere; compare the printed Dice trajectories afterwards.
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,8 +26,14 @@ ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 LR = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-3
+SIDE = sys.argv[5] if len(sys.argv) > 5 else 'both'
+EVERY = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
-_native.load(); nn.set_default_device('cuda:0')
+if SIDE == 'oracle':                      # no GPU: build the (identically seeded) model on the CPU stand-in just to export weights
+    from tests import cpu_backend as _cb
+    _cb.install(); nn.set_default_device('cpu')
+else:
+    _native.load(); nn.set_default_device('cuda:0')
 conf = Hh.make_conf(dafnet_config_chaos, H, batch_size=B, lr=LR)
 conf.d_mask_params['lr'] = LR; conf.d_image_params['lr'] = LR
 model = DAFNet(conf); model.build()
@@ -74,18 +83,23 @@ def dice_of(masks_pred, masks_true):
 def evaluate():
     x1, x2 = val.get_images_modi(0), val.get_images_modi(1)
     m1, m2 = val.get_masks_modi(0), val.get_masks_modi(1)
-    pp = [model.Segmentor.predict(model.Encoders_Anatomy[i].predict(x)) for i, x in enumerate((x1, x2))]
-    with torch.no_grad():
-        po = [OM.segmentor(orc.enc(T(x), i), orc.P, False, None).numpy() for i, x in enumerate((x1, x2))]
-    return [dice_of(pp[0], m1), dice_of(pp[1], m2)], [dice_of(po[0], m1), dice_of(po[1], m2)]
+    dp_, do_ = [float('nan')] * 2, [float('nan')] * 2
+    if SIDE != 'oracle':
+        pp = [model.Segmentor.predict(model.Encoders_Anatomy[i].predict(x)) for i, x in enumerate((x1, x2))]
+        dp_ = [dice_of(pp[0], m1), dice_of(pp[1], m2)]
+    if SIDE != 'product':
+        with torch.no_grad():
+            po = [OM.segmentor(orc.enc(T(x), i), orc.P, False, None).numpy() for i, x in enumerate((x1, x2))]
+        do_ = [dice_of(po[0], m1), dice_of(po[1], m2)]
+    return dp_, do_
 
 
 t0 = time.time()
 for it in range(ITERS):
     d = batch()
-    lp = product_step(d)
-    lo = orc.train_batch(Hh.to_torch(d, torch.float64), supervised=True)['supervised_Mask']
-    if it % 10 == 0 or it == ITERS - 1:
+    lp = product_step(d) if SIDE != 'oracle' else float('nan')
+    lo = orc.train_batch(Hh.to_torch(d, torch.float64), supervised=True)['supervised_Mask'] if SIDE != 'product' else float('nan')
+    if it % EVERY == 0 or it == ITERS - 1:
         dp_, do_ = evaluate()
         print('iter %3d  seg loss product %.4f oracle %.4f | val Dice product %.4f %.4f  oracle %.4f %.4f  |diff| %.4f %.4f  (%.0f s)'
               % (it, lp, lo, dp_[0], dp_[1], do_[0], do_[1], abs(dp_[0] - do_[0]), abs(dp_[1] - do_[1]), time.time() - t0), flush=True)
