@@ -105,6 +105,71 @@ __global__ void tps_warp_bwd_kernel(const float* __restrict__ vol, const float* 
     if (dloc) { dloc[((size_t)b * HW + p) * 2] = gx; dloc[((size_t)b * HW + p) * 2 + 1] = gy; }
 }
 
+// Tiled variant of the data-gradient scatter: a block owns a 16 x 16 tile of OUTPUT pixels and pre-accumulates their taps in an
+// LDS window of 32 x 32 source pixels around the tile (the warp is smooth: displacements beyond 8 pixels are rare and fall
+// back to global atomics), then flushes only the touched entries -- ~3x fewer 64-bit global atomics than one per tap.
+// Same fixed-point integer accumulation, hence the same bits as the untiled kernel.
+#define TPS_TILE 16
+#define TPS_WIN 32
+template <int C>
+__global__ __launch_bounds__(256) void tps_warp_bwd_tiled_kernel(const float* __restrict__ vol, const float* __restrict__ loc,
+                                                                 const float* __restrict__ dout, unsigned long long* __restrict__ dvol,
+                                                                 float* __restrict__ dloc, int H, int W) {
+    __shared__ unsigned long long win[TPS_WIN * TPS_WIN * C];        // 64 KB
+    const int b = blockIdx.z;
+    const int ty0 = blockIdx.y * TPS_TILE, tx0 = blockIdx.x * TPS_TILE;
+    const int wy0 = ty0 - (TPS_WIN - TPS_TILE) / 2, wx0 = tx0 - (TPS_WIN - TPS_TILE) / 2;
+    for (int i = threadIdx.x; i < TPS_WIN * TPS_WIN * C; i += 256) win[i] = 0ull;
+    __syncthreads();
+    const int HW = H * W;
+    const int y = ty0 + (threadIdx.x >> 4), x0 = tx0 + (threadIdx.x & 15);
+    unsigned long long* dvb = dvol + (size_t)b * HW * C;
+    if (y < H && x0 < W) {
+        const int p = y * W + x0;
+        const float x = loc[((size_t)b * HW + p) * 2], yy = loc[((size_t)b * HW + p) * 2 + 1];
+        const float fxf = floorf(x), fyf = floorf(yy);
+        const float ax = x - fxf, ay = yy - fyf;
+        const int fx = (int)fminf(fmaxf(fxf, -2.f), (float)W), fy = (int)fminf(fmaxf(fyf, -2.f), (float)H);
+        const float* vb = vol + (size_t)b * HW * C;
+        float g[C];
+        const float* go = dout + ((size_t)b * HW + p) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] = go[c];
+        float gx = 0.f, gy = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int xi = fx + (t & 1), yi = fy + (t >> 1);
+            if (xi >= 0 && xi < W && yi >= 0 && yi < H) {
+                const float wx = (t & 1) ? ax : 1.f - ax, wy = (t >> 1) ? ay : 1.f - ay;
+                const float sx = (t & 1) ? 1.f : -1.f, sy = (t >> 1) ? 1.f : -1.f;
+                const float* src = vb + ((size_t)yi * W + xi) * C;
+                const int ly = yi - wy0, lx = xi - wx0;
+                const bool inwin = (unsigned)ly < (unsigned)TPS_WIN && (unsigned)lx < (unsigned)TPS_WIN;
+                float dot = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    dot += g[c] * src[c];
+                    const unsigned long long v = (unsigned long long)__double2ll_rn((double)(g[c] * wx * wy) * TPS_FX_SCALE);
+                    if (inwin) atomicAdd(&win[(ly * TPS_WIN + lx) * C + c], v);
+                    else atomicAdd(dvb + ((size_t)yi * W + xi) * C + c, v);
+                }
+                gx += dot * sx * wy;
+                gy += dot * sy * wx;
+            }
+        }
+        if (dloc) { dloc[((size_t)b * HW + p) * 2] = gx; dloc[((size_t)b * HW + p) * 2 + 1] = gy; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TPS_WIN * TPS_WIN * C; i += 256) {
+        const unsigned long long v = win[i];
+        if (v != 0ull) {
+            const int c = i % C, q = i / C;
+            const int yi = wy0 + q / TPS_WIN, xi = wx0 + q % TPS_WIN;       // in range by construction (only valid taps were added)
+            atomicAdd(dvb + ((size_t)yi * W + xi) * C + c, v);
+        }
+    }
+}
+
 __global__ void tps_fx_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         out[i] = (float)((double)acc[i] * (1.0 / TPS_FX_SCALE));
@@ -162,7 +227,12 @@ int mmseg_tps_warp_bwd(const float* vol, const float* loc, const float* Mb, cons
     const long n = (long)B * H * W * C;
     unsigned long long* acc64 = dvol ? reinterpret_cast<unsigned long long*>(acc) : nullptr;
     if (dvol) hipLaunchKernelGGL(tps_zero_kernel, dim3(2048), dim3(256), 0, st, acc64, n);
-    hipLaunchKernelGGL(tps_warp_bwd_kernel<8>, grid, dim3(256), 0, st, vol, loc, dout, acc64, dtheta ? dloc : (float*)nullptr, H, W);
+    if (dvol) {
+        const dim3 tgrid((W + TPS_TILE - 1) / TPS_TILE, (H + TPS_TILE - 1) / TPS_TILE, B);
+        hipLaunchKernelGGL(tps_warp_bwd_tiled_kernel<8>, tgrid, dim3(256), 0, st, vol, loc, dout, acc64, dtheta ? dloc : (float*)nullptr, H, W);
+    } else {
+        hipLaunchKernelGGL(tps_warp_bwd_kernel<8>, grid, dim3(256), 0, st, vol, loc, dout, acc64, dtheta ? dloc : (float*)nullptr, H, W);
+    }
     if (dvol) hipLaunchKernelGGL(tps_fx_to_float_kernel, dim3(2048), dim3(256), 0, st, (const long long*)acc64, dvol, n);
     if (dtheta) {
         const int per = (H * W + TPS_CHUNKS - 1) / TPS_CHUNKS;
