@@ -4,7 +4,7 @@ identical batches with identical random draws (no teacher forcing), then both ar
 split.  The Rounding layer makes the two trajectories diverge pixel by pixel, so this is a statistical statement, the one the
 north_star asks for: |Dice_product - Dice_oracle| on a fixed synthetic split.
 
-    python tools/dice_parity.py [iterations=60] [size=64] [batch=4] [lr=1e-3] [both|product|oracle] [eval_every=10]
+    python tools/dice_parity.py [iterations=60] [size=64] [batch=4] [lr=1e-3] [both|product|oracle] [eval_every=10] [fp32|bf16|fp16]
 
 `product` / `oracle` run one side only (same seeds, hence the same initial weights, batches and draws): the oracle side needs
 no GPU and can run for hours elsewhere; compare the printed Dice trajectories afterwards.
@@ -28,13 +28,14 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 LR = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-3
 SIDE = sys.argv[5] if len(sys.argv) > 5 else 'both'
 EVERY = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+DTYPE = sys.argv[7] if len(sys.argv) > 7 else 'fp32'          # product side only: fp32 | bf16 | fp16
 torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
 if SIDE == 'oracle':                      # no GPU: build the (identically seeded) model on the CPU stand-in just to export weights
     from tests import cpu_backend as _cb
     _cb.install(); nn.set_default_device('cpu')
 else:
     _native.load(); nn.set_default_device('cuda:0')
-conf = Hh.make_conf(dafnet_config_chaos, H, batch_size=B, lr=LR)
+conf = Hh.make_conf(dafnet_config_chaos, H, batch_size=B, lr=LR, compute_dtype=DTYPE if SIDE != 'oracle' else 'fp32')
 conf.d_mask_params['lr'] = LR; conf.d_image_params['lr'] = LR
 model = DAFNet(conf); model.build()
 orc = OD.DAFNetOracle(Hh.export_dafnet(model, torch.float64), dict(decoder_type='film', lr=LR, d_lr=LR))
