@@ -185,3 +185,26 @@ def test_bitwise_reproducibility_of_a_discriminator_step_and_of_the_convolutions
         steps.append([m.grad_arena.clone() for m in gens] + [m.arena.clone() for m in gens])
     for a, b in zip(*steps):
         assert torch.equal(a, b)
+
+
+def test_the_ctypes_stub_of_INTEGRATION_md_runs():
+    """The hand-written binding shown in INTEGRATION.md (what a maintainer of the reference would add) is executed verbatim
+    and checked against torch's convolution."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    code = re.search(r"```python\n(.*?)```", text, flags=re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                     # the snippet loads the library by its in-tree relative path
+    try:
+        exec(code, ns)
+    finally:
+        os.chdir(cwd)
+    x = rnd(2, 24, 20, 16, seed=51).to(DEV)
+    w = (rnd(3, 3, 16, 32, seed=52) * 0.1).to(DEV)
+    b = rnd(32, seed=53).to(DEV)
+    y = ns['conv3x3_same_relu'](x, w, b)
+    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, padding=1)).permute(0, 2, 3, 1)
+    assert float((y - ref).abs().max()) < 1e-4
