@@ -43,7 +43,10 @@ __global__ void dense_fwd_partial_kernel(const float* __restrict__ x, const floa
     }
 }
 
-// N <= 4 (discriminator head, K = 373248): lanes run along K so that every lane is useful; block = 256 threads x 8 k each
+// N <= 4 (discriminator head, K = 373248): lanes run along K so that every lane is useful.  A block owns SMALLN_KPB
+// consecutive k; with K % 4 == 0 and N == 1 every thread streams 16-byte pieces of the rows (the op is a batched dot product,
+// bound by reading x once), otherwise 4-byte pieces.
+#define SMALLN_KPB 1024
 template <int RB, int NB>
 __global__ __launch_bounds__(256) void dense_fwd_smalln_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                float* __restrict__ part, int R, int K, int N) {
@@ -53,20 +56,34 @@ __global__ __launch_bounds__(256) void dense_fwd_smalln_kernel(const float* __re
     for (int b = 0; b < RB; ++b)
 #pragma unroll
         for (int n = 0; n < NB; ++n) acc[b][n] = 0.f;
-    const int k0 = blockIdx.x * 2048;
-#pragma unroll 4
-    for (int i = 0; i < 8; ++i) {
-        const int k = k0 + i * 256 + threadIdx.x;
+    const int k0 = blockIdx.x * SMALLN_KPB;
+    if (NB == 1 && (K & 3) == 0) {
+        const int k = k0 + 4 * threadIdx.x;
         if (k < K) {
-            float wv[NB];
-#pragma unroll
-            for (int n = 0; n < NB; ++n) wv[n] = n < N ? w[(size_t)k * N + n] : 0.f;
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
 #pragma unroll
             for (int b = 0; b < RB; ++b) {
                 if (b < R) {
-                    const float xv = x[(size_t)b * K + k];
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)b * K + k);
+                    acc[b][0] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+                }
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int i = 0; i < SMALLN_KPB / 256; ++i) {
+            const int k = k0 + i * 256 + threadIdx.x;
+            if (k < K) {
+                float wv[NB];
 #pragma unroll
-                    for (int n = 0; n < NB; ++n) acc[b][n] += xv * wv[n];
+                for (int n = 0; n < NB; ++n) wv[n] = n < N ? w[(size_t)k * N + n] : 0.f;
+#pragma unroll
+                for (int b = 0; b < RB; ++b) {
+                    if (b < R) {
+                        const float xv = x[(size_t)b * K + k];
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) acc[b][n] += xv * wv[n];
+                    }
                 }
             }
         }
@@ -156,7 +173,7 @@ __global__ void dense_wgrad_kernel(const float* __restrict__ x, const float* __r
 extern "C" {
 
 long mmseg_dense_workspace_floats(int R, int K, int N) {
-    const long a = (long)dense_kslices(K) * R * N, b = (long)((K + 2047) / 2048) * R * N;
+    const long a = (long)dense_kslices(K) * R * N, b = (long)((K + SMALLN_KPB - 1) / SMALLN_KPB) * R * N;
     return a > b ? a : b;
 }
 
@@ -164,9 +181,11 @@ int mmseg_dense_fwd(const float* x, const float* w, const float* bias, float* y,
                     float alpha, void* stream) {
     if (R < 1 || R > 32) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    if (N <= 4 && R <= 16 && K >= 4096) {
-        const int nb = (K + 2047) / 2048;
-        if (R <= 8) {
+    if (N <= 4 && (R <= 16 || N == 1) && K >= 4096) {
+        const int nb = (K + SMALLN_KPB - 1) / SMALLN_KPB;
+        if (R > 16) {
+            hipLaunchKernelGGL((dense_fwd_smalln_kernel<32, 1>), dim3(nb), dim3(256), 0, st, x, w, ws, R, K, N);
+        } else if (R <= 8) {
             if (N == 1) hipLaunchKernelGGL((dense_fwd_smalln_kernel<8, 1>), dim3(nb), dim3(256), 0, st, x, w, ws, R, K, N);
             else hipLaunchKernelGGL((dense_fwd_smalln_kernel<8, 4>), dim3(nb), dim3(256), 0, st, x, w, ws, R, K, N);
         } else {
