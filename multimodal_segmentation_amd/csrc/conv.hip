@@ -1205,6 +1205,26 @@ __global__ void wflip_kernel(const float* __restrict__ w, float* __restrict__ wt
     }
 }
 
+// mode 0 as a tiled transpose: per tap the [Cin][Cout] matrix goes to rows co of out[Cout][ntaps * Cin] at column tap*Cin + ci;
+// 32 x 32 tiles through LDS, so both the reads (along co) and the writes (along ci) are coalesced
+__global__ void wprep_fwd_tiled_kernel(const float* __restrict__ w, float* __restrict__ out, int ntaps, int Cin, int Cout) {
+    __shared__ float t[32][33];
+    const int tap = blockIdx.z;
+    const float* src = w + (size_t)tap * Cin * Cout;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        t[r][tx] = (ci < Cin && co < Cout) ? src[(size_t)ci * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    const size_t K = (size_t)ntaps * Cin;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < Cout && ci < Cin) out[(size_t)co * K + (size_t)tap * Cin + ci] = t[tx][r];
+    }
+}
+
 // weight re-layouts for the fast path: out[n][tap'][c] with n the GEMM column (output channel of the launch)
 //   mode 0 (forward)      : out[co][tap][ci] = w[tap][ci][co]
 //   mode 1 (data gradient): out[ci][tap][co] = w[ntaps-1-tap][ci][co]
@@ -1427,6 +1447,11 @@ int mmseg_conv2d_fast_path(int C1, int C2, int Cout, int transposed) {
 // mode 0: forward layout [Cout][KH*KW][Cin]; mode 1: data-gradient layout [Cin][KH*KW flipped][Cout]
 int mmseg_conv2d_wprep(const float* w, float* out, int KH, int KW, int Cin, int Cout, int mode, void* stream) {
     const long n = (long)KH * KW * Cin * Cout;
+    if (mode == 0 && KH * KW <= 65535) {
+        const dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, KH * KW);
+        hipLaunchKernelGGL(wprep_fwd_tiled_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, out, KH * KW, Cin, Cout);
+        return MMSEG_CHECK_LAUNCH();
+    }
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wprep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH * KW, Cin, Cout, mode);
