@@ -30,6 +30,7 @@ import torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); never the 2:1-sparsity figure
+DTYPE_NAME = {'f32': 'fp32', 'bf16': 'bf16 MFMA operands (fp32 accumulate)', 'f16': 'fp16 MFMA operands (fp32 accumulate)'}
 TFLOP_PER_PAIR = {('film', 256): 1.630, ('spade', 256): 2.871, ('mmsdnet', 256): 1.469, ('mmsdnet', 320): 2.296}   # BASELINE.md section 4 (conv MACs x 2)
 
 
@@ -181,6 +182,20 @@ def cpu_baseline(H, decoder, B, limit_s=240):
                           % (H, H, B, limit_s, type(exc).__name__)}
 
 
+def launch_ranks(n):
+    """start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child; -> its return code"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 _T0 = time.perf_counter()
 
 
@@ -213,14 +228,23 @@ def main():
         print(json.dumps(cpu_baseline_measure(args.size, args.decoder, args.batch)))
         return
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` on its own: this parent has not touched the GPU (no torch.cuda call so far) and starts the
+        # N ranks as a CHILD process (never exec from a process that may own a GPU context), relays their output and exits with
+        # the child's return code
+        sys.exit(launch_ranks(args.gpus))
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from multimodal_segmentation_amd import nn, _native
     from multimodal_segmentation_amd.configuration import dafnet_config_chaos, dafnet_spade_config_chaos
@@ -311,18 +335,19 @@ def main():
     line = {
         'metric': '2D slices/sec %s train step, %dx%dx2-modality bs=%d/GPU' % ('DAFNet' if args.model == 'dafnet' else 'MMSDNet',
                                                                                 H, H, args.batch),
-        'value': value, 'unit': 'paired slices/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'value': value, 'unit': 'paired slices/s', 'n_gpus': (dist.get_world_size() if world > 1 else 1),
+        'rccl_ranks': (dist.get_world_size() if world > 1 else 0), 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'DAFNet-%s (dafnet%s_config_chaos) %dx%d 2-modality training iteration: generator fit + '
-                               '2 mask-D fits + 2 image-D fits incl. fake pools, bs=%d/GPU, fp32, l_mix=%g'
-                               % (args.decoder, '' if args.decoder == 'film' else '_spade', H, H, args.batch, args.l_mix),
+                               '2 mask-D fits + 2 image-D fits incl. fake pools, bs=%d/GPU, %s, l_mix=%g'
+                               % (args.decoder, '' if args.decoder == 'film' else '_spade', H, H, args.batch, DTYPE_NAME[args.dtype], args.l_mix),
                    'global_batch': world * args.batch, 'parallelism': 'dp%d' % world},
     }
     if args.model == 'mmsdnet':
         line['config']['workload'] = ('MMSDNet (mmsdnet_config_chaos) %dx%d 2-modality training iteration: generator fit + '
-                                      'Z-regressor fit + mask-D fit incl. the fake pool, bs=%d/GPU, fp32, l_mix=%g'
-                                      % (H, H, args.batch, args.l_mix))
+                                      'Z-regressor fit + mask-D fit incl. the fake pool, bs=%d/GPU, %s, l_mix=%g'
+                                      % (H, H, args.batch, DTYPE_NAME[args.dtype], args.l_mix))
     key = (args.decoder if args.model == 'dafnet' else 'mmsdnet', H)
     if key in TFLOP_PER_PAIR:
         line['conv_tflops_whole_step'] = TFLOP_PER_PAIR[key] * value / world
@@ -334,9 +359,9 @@ def main():
         if os.path.exists(tpath) and (args.decoder, H, args.batch, args.l_mix) == ('film', 256, 8, 1.0):
             traffic = json.load(open(tpath))     # HBM bytes per launch from rocprofv3 PMC passes of this same workload
         k = summ.get('conv_fwd_kernel')
+        peak = BF16_MFMA_PEAK_TFLOPS if args.dtype in ('bf16', 'f16') else FP32_MFMA_PEAK_TFLOPS
         if k:
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
-            peak = BF16_MFMA_PEAK_TFLOPS if args.dtype in ('bf16', 'f16') else FP32_MFMA_PEAK_TFLOPS
             line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (implicit-GEMM %s MFMA; forward + data-gradient launches)'
                                                            % ('%s (fp32 tensors in HBM, fp32 accumulation)' % args.dtype if args.dtype != 'f32' else 'fp32'),
                                 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
@@ -351,7 +376,7 @@ def main():
         if w:
             ach = w['flops'] / (w['ms'] * 1e-3) / 1e12
             line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv_wgrad_kernel (+ slab reduce)', 'achieved': ach,
-                                      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                                      'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                                       'traffic': traffic.get('conv_wgrad', {}).get('hbm_bytes_per_launch'),
                                       'algorithmic_bytes_per_launch': w['bytes'] / w['launches'],
                                       'launches': timer.counts.get('conv_wgrad_kernel', w['launches']), 'timed_launches': w['launches'],

@@ -175,7 +175,10 @@ int mmseg_segloss_stats_floats(int B);
 int mmseg_segloss_coef_floats(int B, int C);
 int mmseg_segloss_class_offset(int B);
 int mmseg_segloss_stats(const float* pred, const float* target, float* stats, float* ws, int B, long HW, int C, int nm, void* stream);
-int mmseg_segloss_finalize(const float* stats, float* loss, float* coef, int B, int C, float n_pix_global, float lambda_bce, void* stream);
+/* n_pix_global normalises the loss value (pixels of the whole data-parallel batch); n_pix_grad normalises the gradient
+ * coefficients (the LOCAL pixel count: the gradient all-reduce takes the mean over ranks).  Equal on one device. */
+int mmseg_segloss_finalize(const float* stats, float* loss, float* coef, int B, int C, float n_pix_global, float n_pix_grad,
+                           float lambda_bce, void* stream);
 int mmseg_segloss_grad(const float* pred, const float* target, const float* coef, float* dpred, int B, long HW, int C, int nm,
                        float scale, int use_bce, void* stream);
 /* ---- in-graph per-sample loss terms of the automated-pairing trainers (csrc/pairloss.hip): model_components/balancer.py:33-38

@@ -61,9 +61,12 @@ __global__ void segloss_stats_final_kernel(const float* __restrict__ part, float
         stats[B * 3 + t] = a;
     }
 }
-// loss value + gradient coefficients.  coef: [B][2] dice (a_b, b_b: d/dp = a_b * t + b_b), then [C] w_c, [C] k_c
+// loss value + gradient coefficients.  n_pix_global: pixel count of the WHOLE (all-rank) batch, normalises the loss value;
+// n_pix_grad: pixel count the gradient coefficients are normalised with -- the LOCAL count under data parallelism, because the
+// gradient all-reduce averages over ranks (mean of local-normalised seeds == gradient of the global-batch loss).
+//  coef: [B][2] dice (a_b, b_b: d/dp = a_b * t + b_b), then [C] w_c, [C] k_c
 __global__ void segloss_finalize_kernel(const float* __restrict__ stats, float* __restrict__ loss, float* __restrict__ coef,
-                                        int B, int C, float n_pix_global, float lambda_bce) {
+                                        int B, int C, float n_pix_global, float n_pix_grad, float lambda_bce) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float dice = 0.f;
     for (int b = 0; b < B; ++b) {
@@ -85,8 +88,8 @@ __global__ void segloss_finalize_kernel(const float* __restrict__ stats, float* 
         for (int c = 0; c < C; ++c) {
             const float w = T / (n[c] + 1e-12f);
             bce -= w * S[c];
-            coef[2 * B + c] = -lambda_bce / n_pix_global * w;
-            coef[2 * B + C + c] = -lambda_bce / n_pix_global * (sumq - S[c] * T / ((n[c] + 1e-12f) * (n[c] + 1e-12f)));
+            coef[2 * B + c] = -lambda_bce / n_pix_grad * w;
+            coef[2 * B + C + c] = -lambda_bce / n_pix_grad * (sumq - S[c] * T / ((n[c] + 1e-12f) * (n[c] + 1e-12f)));
         }
         bce /= n_pix_global;
     }
@@ -160,8 +163,8 @@ int mmseg_segloss_stats(const float* pred, const float* target, float* stats, fl
     hipLaunchKernelGGL(segloss_stats_final_kernel, dim3(1), dim3(1024), 0, st, (const float*)ws, stats, B);
     return MMSEG_CHECK_LAUNCH();
 }
-int mmseg_segloss_finalize(const float* stats, float* loss, float* coef, int B, int C, float n_pix_global, float lambda_bce, void* stream) {
-    hipLaunchKernelGGL(segloss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, loss, coef, B, C, n_pix_global, lambda_bce);
+int mmseg_segloss_finalize(const float* stats, float* loss, float* coef, int B, int C, float n_pix_global, float n_pix_grad, float lambda_bce, void* stream) {
+    hipLaunchKernelGGL(segloss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, loss, coef, B, C, n_pix_global, n_pix_grad, lambda_bce);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_segloss_grad(const float* pred, const float* target, const float* coef, float* dpred, int B, long HW, int C, int nm,

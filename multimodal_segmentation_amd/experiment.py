@@ -16,6 +16,7 @@ import subprocess
 
 import numpy as np
 
+from .parallel import dp
 from .utils.config import EasyDict
 
 _PKG = __package__
@@ -89,7 +90,10 @@ class Experiment(object):
         self.save_config(conf)
         return conf
 
+
     def save_config(self, conf):
+        if not dp.is_main():                      # data parallel: rank 0 owns the run folder
+            return
         os.makedirs(conf.folder, exist_ok=True)
         with open(os.path.join(conf.folder, 'experiment_configuration.json'), 'w') as f:
             json.dump(dict(conf.items()), f, default=_jsonable)
@@ -100,10 +104,11 @@ class Experiment(object):
         os.makedirs(conf.folder, exist_ok=True)
         root = logging.getLogger()
         root.setLevel(logging.DEBUG)
-        fh = logging.FileHandler(os.path.join(conf.folder, 'logfile.log'))
-        fh.setFormatter(logging.Formatter('%(asctime)s %(message)s'))
-        root.addHandler(fh)
-        root.addHandler(logging.StreamHandler())
+        if dp.is_main():
+            fh = logging.FileHandler(os.path.join(conf.folder, 'logfile.log'))
+            fh.setFormatter(logging.Formatter('%(asctime)s %(message)s'))
+            root.addHandler(fh)
+            root.addHandler(logging.StreamHandler())
         self.log = root
         root.debug(conf.items())
         root.info('---- Setting up experiment at ' + conf.folder + '----')
@@ -112,6 +117,7 @@ class Experiment(object):
     def get_executor(self, conf, test=False):
         model = resolve('models', conf.model)(conf)
         model.build()
+        dp.sync_model(model)                      # data parallel: every replica starts from rank 0's weights
         return resolve('model_executors', conf.executor)(conf, model)
 
     def run_experiment(self, conf, test):
@@ -119,10 +125,15 @@ class Experiment(object):
         if not test:
             executor.train()
             self.save_config(conf)               # training adds keys (e.g. unlabelled counts)
-        executor.test()
+        if dp.is_main():                          # replicas are identical after training: one rank evaluates and writes
+            executor.test()
+        dp.barrier()
 
     def run(self, argv=None):
         args = parse_arguments(argv)
+        # one process per GPU under `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE): join the RCCL group and
+        # shard the slice pairs across ranks (parallel/dp.py); a plain `python experiment.py` run is single-GPU
+        dp.init_from_env()
         conf = self.get_config(int(args.split), args)
         self.init_logging(conf)
         self.run_experiment(conf, args.test)

@@ -21,6 +21,7 @@ from ..loaders import synthetic
 from ..model_components import anatomy_encoder, modality_encoder, anatomy_fuser, segmentor, decoder, balancer
 from ..model_tester import ModelTester
 from ..models.discriminator import Discriminator
+from ..parallel import dp
 from ..utils import data_utils
 from ..utils.distributions import NormalDistribution
 from .base_executor import Executor, EarlyStopping
@@ -69,6 +70,15 @@ class DAFNetExecutor(Executor):
         for swa, live in pairs:
             if swa is not None:
                 swa.model = live
+
+    def _all_models(self):
+        m = self.model
+        ms = list(m._generator_models())
+        for name in ('D_Mask', 'D_Image1', 'D_Image2', 'Balancer'):
+            x = getattr(m, name, None)
+            if x is not None and x not in ms:
+                ms.append(x)
+        return ms
 
     def get_swa_models(self):
         return [s for s in (self.swa_D_Mask, self.swa_D_Image1, self.swa_D_Image2, self.swa_Enc_Anatomy1,
@@ -150,19 +160,21 @@ class DAFNetExecutor(Executor):
     def train(self):
         log.info('Training Model')
         self.init_train_data(slices_per_volume=self.conf.get('slices_per_volume', 20))
-        if not os.path.exists(self.conf.folder):
-            os.makedirs(self.conf.folder)
+        os.makedirs(self.conf.folder, exist_ok=True)
         es = EarlyStopping('val_loss_mod2_fused', min_delta=0.01, patience=60)
         loss_names = self.get_loss_names()
         total_loss = {n: [] for n in loss_names}
         csv_path = self.conf.folder + '/training.csv'
-        with open(csv_path, 'w') as f:
-            f.write('epoch,' + ','.join(loss_names) + '\n')
+        main = dp.is_main()                    # data parallel: rank 0 writes the csv and the checkpoints
+        if main:
+            with open(csv_path, 'w') as f:
+                f.write('epoch,' + ','.join(loss_names) + '\n')
         for self.epoch in range(self.conf.epochs):
             log.info('Epoch %d/%d' % (self.epoch, self.conf.epochs))
             epoch_loss = {n: [] for n in loss_names}
             for self.batch in range(self.batches):
                 self.train_batch(epoch_loss)
+            dp.average_state(self._all_models())     # replicas leave the epoch with identical BatchNorm moving statistics
             self.set_swa_model_weights()
             for swa_m in self.get_swa_models():
                 swa_m.on_epoch_end(self.epoch)
@@ -172,8 +184,9 @@ class DAFNetExecutor(Executor):
             logs = {l: total_loss[l][-1] for l in loss_names}
             log.info(str('Epoch %d/%d: ' + ', '.join([l + ' Loss = %.5f' for l in loss_names])) %
                      ((self.epoch, self.conf.epochs) + tuple(total_loss[l][-1] for l in loss_names)))
-            with open(csv_path, 'a') as f:
-                f.write('%d,' % self.epoch + ','.join('%.6f' % logs[l] for l in loss_names) + '\n')
+            if main:
+                with open(csv_path, 'a') as f:
+                    f.write('%d,' % self.epoch + ','.join('%.6f' % logs[l] for l in loss_names) + '\n')
             self.save_models()
             if self.stop_criterion(es, logs):
                 log.info('Finished training from early stopping criterion')
@@ -185,6 +198,8 @@ class DAFNetExecutor(Executor):
 
     def save_models(self, postfix=''):
         """Checkpoints hold the SWA clones, one file per component under <folder>/models/ (dafnet_executor.py:286-301)"""
+        if not dp.is_main():
+            return
         model_folder = self.conf.folder + '/models/'
         if not os.path.exists(model_folder):
             os.makedirs(model_folder)

@@ -10,7 +10,6 @@ False), dafnet.py:119-121) and trained by their own trainers (dafnet.py:75-115, 
 """
 import logging
 import os
-import traceback
 
 from .. import costs, nn, ops
 from ..model_components import anatomy_fuser, modality_encoder, segmentor, decoder, balancer
@@ -38,11 +37,10 @@ class DAFNet(MMSDNet):
         self.build_image_discriminator2()
         self.build_generators()
         self.apply_loss_scale()
-        try:
-            self.load_models()
-        except Exception:
-            log.warning('No models found')
-            traceback.print_exc()
+        # only a MISSING checkpoint means "start from scratch" (load_models returns quietly); an unreadable or mismatched
+        # one raises instead of silently training from random weights (the reference swallows every exception here,
+        # dafnet.py:47-52)
+        self.load_models()
 
     # ---- checkpoint layout <folder>/models/<component> (dafnet.py:54-73) ----------------------------------------------
     def _checkpoint_items(self):
@@ -58,10 +56,8 @@ class DAFNet(MMSDNet):
         log.info('Loading trained models from file')
         for fname, m in self._checkpoint_items():
             m.load_weights(model_folder + fname)
-        try:
+        if self.Balancer is not None and os.path.exists(model_folder + 'Balancer'):
             self.Balancer.load_weights(model_folder + 'Balancer')
-        except Exception:
-            pass
 
     def save_models(self, postfix=''):
         model_folder = self.conf.folder + '/models/'

@@ -726,8 +726,10 @@ def seg_loss(pred, target, num_masks, lambda_bce, scale, class_sum_hook=None, n_
         class_sum_hook(stats[N.call('mmseg_segloss_class_offset', B):])
     loss = _new((1,), pred)
     coef = _new((N.call('mmseg_segloss_coef_floats', B, C),), pred)
-    npg = float(B * H * W if n_pix_global is None else n_pix_global)
-    N.call('mmseg_segloss_finalize', stats, loss, coef, B, C, npg, float(lambda_bce))
+    npl = float(B * H * W)
+    npg = npl if n_pix_global is None else float(n_pix_global)
+    # loss value over the global pixel count; gradient seeds over the LOCAL one (the DP all-reduce averages over ranks)
+    N.call('mmseg_segloss_finalize', stats, loss, coef, B, C, npg, npl, float(lambda_bce))
     dpred = None
     if want_grad:
         dpred = _new(pred.shape, pred)

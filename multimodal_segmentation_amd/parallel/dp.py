@@ -38,6 +38,70 @@ def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
+def is_main():
+    """rank 0 (or no process group): the only rank that writes checkpoints, csv files and logs"""
+    return rank() == 0
+
+
+def init_from_env(backend=None):
+    """One process per GPU, launched by `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment): bind this process to its GPU, join the RCCL ("nccl") group and switch data parallelism on.  Returns
+    (rank, local_rank, world).  Without WORLD_SIZE > 1 in the environment this is a no-op returning (0, LOCAL_RANK or 0, 1).
+    Must run before the models are built (they are allocated on the default device)."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world <= 1:
+        return 0, local_rank, 1
+    use_gpu = torch.cuda.is_available()
+    backend = backend or ('nccl' if use_gpu else 'gloo')
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        kw = {'device_id': torch.device('cuda', local_rank)} if (use_gpu and backend == 'nccl') else {}
+        dist.init_process_group(backend, **kw)
+    if use_gpu:
+        from .. import nn
+        nn.set_default_device('cuda:%d' % local_rank)
+    enable(True)
+    return dist.get_rank(), local_rank, dist.get_world_size()
+
+
+def sync_model(model):
+    """broadcast every component of a DAFNet / MMSDNet wrapper from rank 0 (weights, BatchNorm moving statistics, the
+    spectral regularisers' u0)"""
+    if not enabled():
+        return
+    ms = list(model._generator_models())
+    for name in ('D_Mask', 'D_Image1', 'D_Image2', 'Balancer'):
+        m = getattr(model, name, None)
+        if m is not None and m not in ms:
+            ms.append(m)
+    broadcast_models(ms)
+
+
+def barrier():
+    if enabled():
+        dist.barrier()
+
+
+def average_state(models):
+    """all-reduce(mean) of the non-trainable state (BatchNorm moving statistics; the spectral u0 are equal already) so that
+    the replicas -- which normalise with per-rank batch statistics during an epoch -- validate, early-stop and checkpoint
+    identically at the epoch boundary"""
+    if not enabled():
+        return
+    from .. import ops
+    ws = float(dist.get_world_size())
+    for m in models:
+        t = m.state_arena
+        if t is not None and t.numel() > 0:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            ops.axpby(t, t, 1.0 / ws, 0.0, out=t)
+    ops.bump_weight_version()
+
+
 def class_sum_hook():
     if not enabled():
         return None

@@ -428,7 +428,7 @@ def segloss_stats(pred, target, stats, ws, B, HW, C, nm):
     stats.copy_(st); return 0
 
 
-def segloss_finalize(stats, loss, coef, B, C, n_pix_global, lambda_bce):
+def segloss_finalize(stats, loss, coef, B, C, n_pix_global, n_pix_grad, lambda_bce):
     I, T, P = stats[0:3 * B:3], stats[1:3 * B:3], stats[2:3 * B:3]
     den, num = T + P + 1e-12, 2 * I + 1e-12
     dice = (1 - num / den).mean()
@@ -442,8 +442,8 @@ def segloss_finalize(stats, loss, coef, B, C, n_pix_global, lambda_bce):
         w = Tt / (n + 1e-12)
         bce = -(w * S).sum() / n_pix_global
         sumq = (S / (n + 1e-12)).sum()
-        cf[2 * B:2 * B + C] = -lambda_bce / n_pix_global * w
-        cf[2 * B + C:2 * B + 2 * C] = -lambda_bce / n_pix_global * (sumq - S * Tt / (n + 1e-12) ** 2)
+        cf[2 * B:2 * B + C] = -lambda_bce / n_pix_grad * w
+        cf[2 * B + C:2 * B + 2 * C] = -lambda_bce / n_pix_grad * (sumq - S * Tt / (n + 1e-12) ** 2)
     loss.copy_((dice + lambda_bce * bce).reshape(1)); coef.copy_(cf); return 0
 
 

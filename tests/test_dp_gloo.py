@@ -38,6 +38,30 @@ def _build():
     return conf, model, Hh
 
 
+def _tiny_seg_trainer():
+    """BN-free segmentation head (1x1 conv 8 -> 5 + softmax) under the DAFNet segmentation loss (Dice + 0.01 * swapped BCE, weight
+    10): per-sample arithmetic only, so 2 ranks x batch 1 must give the single-process gradient of the batch of 2."""
+    from multimodal_segmentation_amd import nn, ops
+    from multimodal_segmentation_amd.models.trainer import Trainer, OutputSpec
+
+    class Tiny(nn.Model):
+        def __init__(self):
+            super(Tiny, self).__init__('TinySeg')
+            nn.conv_params(self, 'c', 1, 8, 5)
+            self.finalize(np.random.RandomState(3))
+
+        def forward(self, x, training=False):
+            return ops.softmax(nn.conv(self, 'c', x))
+    m = Tiny()
+    tr = Trainer('tiny', lambda ins, training=True: [m(ins[0])], [OutputSpec('Segmentor', 'dice_bce', 10.0)], [m],
+                 nn.Adam(1e-4), num_masks=4)
+    return m, tr
+
+
+def _tiny_input(B):
+    return np.random.RandomState(11).standard_normal((B, H, H, 8)).astype(np.float32)
+
+
 def _worker(rank, world, port, q):
     try:
         _worker_body(rank, world, port, q)
@@ -72,10 +96,16 @@ def _worker_body(rank, world, port, q):
                                  eps=[d['eps1'][sl], d['eps2'][sl]])
     # every generator arena was all-reduced while the backward pass was still being queued (overlap), none at the end
     assert dp._state['last_overlapped'] == len(gens) == dp._state['last_collectives'], dp._state
+    # ---- combined Dice + swapped-argument BCE on a BN-free head: the averaged gradient must be the global-batch gradient ----
+    tiny, ttr = _tiny_seg_trainer()
+    dp.broadcast_models([tiny])
+    s_in = _tiny_input(2)
+    ttr.fit([s_in[sl]], [d['m1'][sl]])
+    tiny_grad = tiny.grad_arena.clone().numpy()
     sig = torch.cat([m.arena.double().sum().reshape(1) for m in gens])
     gathered = [torch.zeros_like(sig) for _ in range(world)]
     dist.all_gather(gathered, sig)
-    q.put((rank, dm_after.numpy(), [g.numpy() for g in gathered], float(h.history['loss'][0])))
+    q.put((rank, dm_after.numpy(), [g.numpy() for g in gathered], float(h.history['loss'][0]), tiny_grad))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,9 +130,25 @@ def test_dp_world2_gloo():
     for a, b in zip(res[0][2], res[1][2]):
         assert np.array_equal(a, b), 'generator replicas diverged'
     # single-process reference on the global batch of 2
+    try:
+        _single_process_reference(res)
+    finally:
+        from tests import cpu_backend as cb
+        cb.uninstall()
+
+
+def _single_process_reference(res):
     conf, model, Hh = _build()
     d = Hh.make_step_data(2, H, H, seed=5)
     model.D_Mask_trainer.fit([d['dm_m1'], d['dm_m2']], [1.0, 0.0])
     ref = model.D_Mask.arena.numpy()
+    # Dice + swapped-argument BCE head: mean of the per-rank gradients == gradient of the loss on the global batch
+    assert np.array_equal(res[0][4], res[1][4])
+    tiny, ttr = _tiny_seg_trainer()
+    ttr.fit([_tiny_input(2)], [d['m1']])
+    gref = tiny.grad_arena.numpy()
+    assert np.abs(res[0][4] - gref).max() < 1e-5 * max(1.0, np.abs(gref).max()), \
+        'DP segmentation-loss gradient differs from the global-batch gradient: %g vs scale %g' % (
+            np.abs(res[0][4] - gref).max(), np.abs(gref).max())
     # after one Adam step |delta| = lr wherever the gradient is not ~0: compare the step direction
     assert np.abs(res[0][1] - ref).max() < 2.5e-4 * 1e-0 * 0 + 2e-6, 'DP D step differs from the global-batch step'
