@@ -1,0 +1,74 @@
+"""The reference's TOP-LEVEL module names as aliases of this package's modules.
+
+The reference is run from its repository root, so its callers import `model_components.decoder`, `models.dafnet`,
+`model_executors.dafnet_executor`, `configuration.dafnet_config_chaos`, `layers.spade`, `loaders.loader_factory`,
+`callbacks.swa`, `costs`, `utils.data_utils`, `model_tester` (experiment.py:113-124 resolves `'models.' + conf.model` and
+`'model_executors.' + conf.executor` with importlib; models/dafnet.py:11-16 does `from model_components import ...`).
+
+    import multimodal_segmentation_amd.compat as compat
+    compat.install()
+    from model_components import decoder               # IS multimodal_segmentation_amd.model_components.decoder
+    importlib.import_module('models.dafnet').DAFNet    # what experiment.py:115-118 does
+
+`install()` puts ONE finder on `sys.meta_path` that answers exactly those names by importing the package-qualified
+module and registering the same module object under the short name -- no second copy of any module exists, so class
+identities, module-level caches and the kernel library handle are shared.  Opt-in: the generic names (`utils`,
+`models`, ...) are only claimed after `install()`; `uninstall()` removes the finder and the aliases.
+"""
+import importlib
+import importlib.abc
+import importlib.machinery
+import sys
+
+_PKG = __name__.rsplit('.', 1)[0]
+TOP_LEVEL = ('model_components', 'models', 'model_executors', 'configuration', 'layers', 'loaders', 'callbacks', 'costs',
+             'utils', 'model_tester')
+
+
+class _AliasLoader(importlib.abc.Loader):
+    def __init__(self, real_name):
+        self.real_name = real_name
+
+    def create_module(self, spec):
+        real = importlib.import_module(self.real_name)      # the one and only module object
+        self.real_spec = real.__spec__
+        return real
+
+    def exec_module(self, module):
+        # already executed under its package-qualified name; importlib has just pointed __spec__ at the alias -- put the real
+        # one back so that relative imports inside the module keep resolving against the package
+        module.__spec__ = self.real_spec
+
+
+class _AliasFinder(importlib.abc.MetaPathFinder):
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname.split('.', 1)[0] not in TOP_LEVEL:
+            return None
+        real_name = _PKG + '.' + fullname
+        try:
+            real = importlib.import_module(real_name)
+        except ModuleNotFoundError as exc:
+            if exc.name == real_name:                        # no such module in the package: let the other finders answer
+                return None
+            raise
+        spec = importlib.machinery.ModuleSpec(fullname, _AliasLoader(real_name), is_package=hasattr(real, '__path__'))
+        return spec
+
+
+_finder = _AliasFinder()
+
+
+def install():
+    """claim the reference's top-level module names (idempotent)"""
+    if _finder not in sys.meta_path:
+        sys.meta_path.insert(0, _finder)
+    return _finder
+
+
+def uninstall():
+    if _finder in sys.meta_path:
+        sys.meta_path.remove(_finder)
+    for name in [n for n in sys.modules if n.split('.', 1)[0] in TOP_LEVEL]:
+        mod = sys.modules[name]
+        if getattr(mod, '__name__', '').startswith(_PKG + '.'):
+            del sys.modules[name]

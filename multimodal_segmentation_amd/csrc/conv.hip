@@ -647,7 +647,7 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (p.M <= 0 || p.Cout <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
     if (p.C1 == 8 && p.C2 == 0 && p.Cout == 8 && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.transposed && !p.ups &&
         p.Ho == p.H && p.Wo == p.W && p.pad_h == 1 && p.pad_w == 1 && p.y2 == nullptr && p.w != nullptr && p.osh == 1 &&
-        p.oscale == nullptr && aligned16(p.x1) && aligned16(p.y)) {
+        p.oscale == nullptr && aligned16(p.x1) && aligned16(p.y) && (long)p.M * 8 * 4 < (1L << 31) - 64) {
         hipLaunchKernelGGL((conv_direct_kernel<8, 8, 3>), dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st,
                            p.x1, p.w, p.bias, p.y, p.B, p.H, p.W, 1, p.act, p.alpha);
         return MMSEG_CHECK_LAUNCH();
@@ -660,6 +660,8 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
                       (long)p.K * p.Cout * 4 < lim;
     const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
     if (omap && !fast) return (int)hipErrorInvalidValue;     // strided output mapping exists on the fast path only
+    if (!fast && p.w == nullptr) return (int)hipErrorInvalidValue;   // the generic kernels read the Keras-layout weights: a caller
+                                                                     // that only prepared `wt` must not fall through to them
     if (fast) {
         if (p.Cout > 64 && tiles_big >= 384) return launch_fast<128, 128, 2, 2>(p, st);
         if (p.Cout > 32) {

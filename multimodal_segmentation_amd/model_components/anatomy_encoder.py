@@ -16,8 +16,8 @@ log = logging.getLogger('anatomy_encoder')
 
 
 def _check(conf):
-    if conf.normalise != 'batch':
-        raise NotImplementedError("anatomy encoder: only normalise='batch' (the value of every reference config)")
+    if conf.normalise not in ('batch', 'instance', None, 'None', 'none'):
+        raise ValueError("anatomy encoder: normalise must be 'batch', 'instance' or None (utils/model_utils.py:6-12)")
     if not (1 <= conf.downsample <= 4):
         raise ValueError('Unet downsample must be in 1..4')
 
@@ -27,8 +27,14 @@ class SharedDecoder(nn.Model):
 
     def __init__(self, conf, rng, name='Enc_Anatomy_shared'):
         super(SharedDecoder, self).__init__(name)
-        unet.declare_unet_up(self, conf.filters, conf.out_channels, conf.downsample)
+        self.norm = _norm_of(conf)
+        unet.declare_unet_up(self, conf.filters, conf.out_channels, conf.downsample, self.norm)
         self.finalize(rng)
+
+
+def _norm_of(conf):
+    """utils/model_utils.normalise: anything but 'instance' / 'batch' is the identity"""
+    return conf.normalise if conf.normalise in ('batch', 'instance') else None
 
 
 class AnatomyEncoder(nn.Model):
@@ -39,9 +45,10 @@ class AnatomyEncoder(nn.Model):
         super(AnatomyEncoder, self).__init__(name)
         _check(conf)
         self.conf = conf
-        unet.declare_unet_down(self, conf.input_shape[-1], conf.filters, conf.downsample)
+        self.norm = _norm_of(conf)
+        unet.declare_unet_down(self, conf.input_shape[-1], conf.filters, conf.downsample, self.norm)
         if shared is None:
-            unet.declare_unet_up(self, conf.filters, conf.out_channels, conf.downsample)
+            unet.declare_unet_up(self, conf.filters, conf.out_channels, conf.downsample, self.norm)
             self.up = self
         else:
             self.up = shared
@@ -53,8 +60,8 @@ class AnatomyEncoder(nn.Model):
 
     def forward(self, x, training=False):
         ds = self.conf.downsample
-        l, skips = unet.unet_downsample(self, x, training, ds)
-        l = unet.unet_bottleneck_upsample(self.up, l, skips, training, ds)
+        l, skips = unet.unet_downsample(self, x, training, ds, self.norm)
+        l = unet.unet_bottleneck_upsample(self.up, l, skips, training, ds, self.norm)
         logits = nn.conv(self.up, 'conv_anatomy', l)
         soft, rounded = ops.softmax_round(logits)        # Conv2D(.., softmax) + Rounding (anatomy_encoder.py:23-25)
         self.last_soft = soft

@@ -31,6 +31,8 @@ class ModalityEncoder(nn.Model):
         nn.dense_params(self, 'z_log_var', 32, conf.num_z)
         self.finalize(rng)
         self.output_shape = [(None, conf.num_z), (None, 1)]
+        self._eps_seed = int(conf.get('seed', 10)) + 104729
+        self._eps_rng = None
 
     def _mean_logvar(self, s, x, want_logvar=True):
         l = nn.conv(self, 'c0', s, stride=2, padding='valid', act='leaky', alpha=0.3, x2=x)
@@ -44,8 +46,14 @@ class ModalityEncoder(nn.Model):
         z_mean, z_log_var = self._mean_logvar(s, x, want_logvar=not mu_only)
         if mu_only:
             return z_mean
-        if eps is None:     # K.random_normal inside the graph (sdnet_utils.py:20): drawn on the host like z samples
-            eps = np.random.normal(0., 1., size=tuple(z_mean.shape)).astype(np.float32)
+        if eps is None:
+            # K.random_normal inside the graph (sdnet_utils.py:20) is TensorFlow's generator, independent of numpy's global
+            # stream (from which the executors draw z samples and pool indices right after a batch): a private generator,
+            # created at the first draw and offset by the data-parallel rank so that replicas sample different noise
+            if self._eps_rng is None:
+                from ..parallel import dp
+                self._eps_rng = np.random.RandomState((self._eps_seed + 7919 * dp.rank()) % (2 ** 32))
+            eps = self._eps_rng.normal(0., 1., size=tuple(z_mean.shape)).astype(np.float32)
         eps = nn.to_device(eps, z_mean.device)
         z, kl = ops.sampling_kl(z_mean, z_log_var, eps)
         return [z, kl]

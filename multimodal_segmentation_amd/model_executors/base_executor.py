@@ -49,7 +49,11 @@ class Executor(object):
                        if p.get(k)]
         if unsupported:
             raise NotImplementedError('augmentations not on the device path: %s' % unsupported)
-        return RotationFlow(arrays, self.conf.batch_size, self.conf.seed, self.device, rotation_range=p['rotation_range'],
+        # data parallel: rank r reseeds the global numpy stream with conf.seed + 7919 r (+ batch index), so shuffles, rotation
+        # angles and the z / pool-index draws that follow a batch differ between replicas; rank 0 follows the reference stream
+        from ..parallel import dp
+        return RotationFlow(arrays, self.conf.batch_size, self.conf.seed + 7919 * dp.rank(), self.device,
+                            rotation_range=p['rotation_range'],
                             order=self.conf.get('augment_interpolation_order', 1))
 
     def validate(self, epoch_loss):

@@ -338,6 +338,32 @@ def conv_bn(m, cname, bname, x, training, relu=False, x2=None, upsample=False):
                                m.params[bname + '/moving_variance'].data, relu=relu, x2=x2, upsample=upsample, wkey=id(w))
 
 
+def norm_params(m, name, c, norm):
+    """parameters of utils/model_utils.normalise(norm) (reference utils/model_utils.py:6-12): BatchNormalization,
+    keras_contrib InstanceNormalization() (axis=None: ONE scalar gamma and beta), or the identity Lambda"""
+    if norm == 'batch':
+        bn_params(m, name, c)
+    elif norm == 'instance':
+        m.add_param(name + '/gamma', (1,), 'ones')
+        m.add_param(name + '/beta', (1,), 'zeros')
+
+
+def conv_norm(m, cname, nname, x, training, relu=False, x2=None, upsample=False, norm='batch'):
+    """Conv2D(3x3 'same') -> normalise(norm) [-> ReLU] (models/unet.py:94-101, utils/model_utils.py:6-22)"""
+    if norm == 'batch':
+        return conv_bn(m, cname, nname, x, training, relu=relu, x2=x2, upsample=upsample)
+    if norm == 'instance':
+        # (x - mean) / (std + 1e-3) over (H, W, C) jointly per sample, then the scalar affine and the activation in the FiLM
+        # kernel (alpha 0 = ReLU, alpha 1 = linear)
+        l = conv(m, cname, x, x2=x2, upsample=upsample)
+        g, b = m.params[nname + '/gamma'], m.params[nname + '/beta']
+        B, C = l.shape[0], l.shape[3]
+        gt = ops.expand_scalar(g.data, B, C, g.g(), anchor(x.device))
+        bt = ops.expand_scalar(b.data, B, C, b.g(), anchor(x.device))
+        return ops.film(ops.instnorm_spade(l), gt, bt, None, 0.0 if relu else 1.0)
+    return conv(m, cname, x, x2=x2, upsample=upsample, act='relu' if relu else None)
+
+
 # ---- Keras 2.1.6 Adam over the arenas of a set of models -------------------------------------------------------
 class Adam(object):
     """keras.optimizers.Adam(lr): beta (0.9, 0.999), epsilon 1e-7, bias correction folded into lr_t.  One instance

@@ -704,6 +704,29 @@ class _InstNormSpade(torch.autograd.Function):
         return dx, dg, db, None
 
 
+class _ExpandScalar(torch.autograd.Function):
+    """A 1-element parameter (the scalar gamma / beta of keras_contrib InstanceNormalization(axis=None)) as a [B, C] table
+    for the FiLM kernel; the backward pass sums the table's gradient into the parameter's gradient-arena slot."""
+
+    @staticmethod
+    def forward(ctx, anchor, p, B, C, grad):
+        ctx.grad = grad
+        return p.reshape(1, 1).expand(B, C).contiguous()
+
+    @staticmethod
+    def backward(ctx, dg):
+        if ctx.grad is not None:
+            dg = _c(dg)
+            ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', dg.numel(), 1), dg.device)
+            N.call('mmseg_colsum', dg.reshape(-1), ctx.grad, ws, dg.numel(), 1, 1.0, 1)
+        _grad_done(ctx.grad)
+        return (None,) * 5
+
+
+def expand_scalar(p, B, C, grad=None, anchor=None):
+    return _ExpandScalar.apply(anchor if grad is not None else None, p, B, C, grad)
+
+
 def instnorm_spade(x, gamma=None, beta=None, act_alpha=-1.0):
     """act( IN(x) * (1 + gamma) + beta ); act_alpha < 0: no activation (layers/spade.py:7-33,51-54)."""
     return _InstNormSpade.apply(x, gamma, beta, act_alpha)

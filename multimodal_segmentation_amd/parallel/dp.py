@@ -22,8 +22,9 @@ import torch.distributed as dist
 _state = {'enabled': False}
 
 
-def enable(flag=True):
-    _state['enabled'] = bool(flag) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+def enable(flag=True, force=False):
+    """`force`: keep the collectives on even with a single rank (used to exercise the RCCL path on a one-GPU box)"""
+    _state['enabled'] = bool(flag) and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
 
 
 def enabled():

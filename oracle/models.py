@@ -64,6 +64,15 @@ class ParamBuilder(object):
         self.P[name + '/kernel'] = torch.tensor(init_kernel(self.rng, (cin, cout), init), dtype=self.dtype)
         self.P[name + '/bias'] = torch.zeros(cout, dtype=self.dtype)
 
+    def norm(self, name, c, norm='batch'):
+        """utils/model_utils.normalise (model_utils.py:6-12): BatchNormalization, keras_contrib InstanceNormalization()
+        (axis=None -> scalar gamma / beta) or the identity"""
+        if norm == 'batch':
+            self.bn(name, c)
+        elif norm == 'instance':
+            self.P[name + '/gamma'] = torch.ones(1, dtype=self.dtype)
+            self.P[name + '/beta'] = torch.zeros(1, dtype=self.dtype)
+
     def bn(self, name, c):
         self.P[name + '/gamma'] = torch.ones(c, dtype=self.dtype)
         self.P[name + '/beta'] = torch.zeros(c, dtype=self.dtype)
@@ -74,33 +83,43 @@ class ParamBuilder(object):
 # ----------------------------------------------------------------------------
 # UNet (models/unet.py:37-101, utils/model_utils.py:15-22)
 # ----------------------------------------------------------------------------
-def _build_conv_block(pb, name, cin, f):
-    pb.conv(name + 'a', 3, cin, f, 'he_normal'); pb.bn(name + 'a_bn', f)
-    pb.conv(name + 'b', 3, f, f, 'he_normal'); pb.bn(name + 'b_bn', f)
+def _build_conv_block(pb, name, cin, f, norm='batch'):
+    pb.conv(name + 'a', 3, cin, f, 'he_normal'); pb.norm(name + 'a_bn', f, norm)
+    pb.conv(name + 'b', 3, f, f, 'he_normal'); pb.norm(name + 'b_bn', f, norm)
+
+
+def _normalise(l, P, name, training, upd):
+    """the layer utils/model_utils.normalise built, told apart by the parameters it owns: 4 -> BatchNormalization, scalar
+    gamma/beta -> keras_contrib InstanceNormalization() over (H, W, C) jointly with (x - mean) / (std + eps), none -> identity"""
+    if name + '/moving_mean' in P:
+        return O.batchnorm(l, P, name, training, upd)
+    if name + '/gamma' in P:
+        return O.instance_norm(l) * P[name + '/gamma'] + P[name + '/beta']
+    return l
 
 
 def _conv_block(x, P, name, training, upd):
     """models/unet.py:94-101."""
     l = O.conv2d(x, P[name + 'a/kernel'], P[name + 'a/bias'])
-    l = torch.relu(O.batchnorm(l, P, name + 'a_bn', training, upd))
+    l = torch.relu(_normalise(l, P, name + 'a_bn', training, upd))
     l = O.conv2d(l, P[name + 'b/kernel'], P[name + 'b/bias'])
-    return torch.relu(O.batchnorm(l, P, name + 'b_bn', training, upd))
+    return torch.relu(_normalise(l, P, name + 'b_bn', training, upd))
 
 
-def build_unet_down(pb, prefix, cin, f):
+def build_unet_down(pb, prefix, cin, f, norm='batch'):
     c = cin
     for i in range(4):
-        _build_conv_block(pb, '%sd%d' % (prefix, i), c, f * 2 ** i)
+        _build_conv_block(pb, '%sd%d' % (prefix, i), c, f * 2 ** i, norm)
         c = f * 2 ** i
 
 
-def build_unet_up(pb, prefix, f, out_channels):
-    _build_conv_block(pb, prefix + 'bott', f * 8, f * 16)
+def build_unet_up(pb, prefix, f, out_channels, norm='batch'):
+    _build_conv_block(pb, prefix + 'bott', f * 8, f * 16, norm)
     c = f * 16
     for i in (3, 2, 1, 0):
         fo = f * 2 ** i
-        pb.conv('%su%d' % (prefix, i), 3, c, fo, 'he_normal'); pb.bn('%su%d_bn' % (prefix, i), fo)
-        _build_conv_block(pb, '%su%dc' % (prefix, i), 2 * fo, fo)
+        pb.conv('%su%d' % (prefix, i), 3, c, fo, 'he_normal'); pb.norm('%su%d_bn' % (prefix, i), fo, norm)
+        _build_conv_block(pb, '%su%dc' % (prefix, i), 2 * fo, fo, norm)
         c = fo
     pb.conv(prefix + 'conv_anatomy', 1, f, out_channels)
 
@@ -124,7 +143,7 @@ def unet_up(l, skips, P, prefix, training, upd, rounding=True, return_presoftmax
     for i in (3, 2, 1, 0):
         n = '%su%d' % (prefix, i)
         l = O.conv2d(O.upsample2(l), P[n + '/kernel'], P[n + '/bias'])
-        l = O.batchnorm(l, P, n + '_bn', training, upd)
+        l = _normalise(l, P, n + '_bn', training, upd)
         l = torch.cat([l, skips[i]], dim=-1)
         l = _conv_block(l, P, n + 'c', training, upd)
     logits = O.conv2d(l, P[prefix + 'conv_anatomy/kernel'], P[prefix + 'conv_anatomy/bias'])

@@ -1,0 +1,80 @@
+"""The data-parallel machinery on the REAL backend: torch.distributed "nccl" (= RCCL) with ONE rank on the GPU box.
+
+With a single rank every all-reduce is the identity, so a step with data parallelism forced on must reproduce the plain
+step BITWISE -- which it only does if the collectives (issued on RCCL's stream from GradTracker in the middle of the
+backward pass) are ordered correctly against the ctypes kernel launches on the compute stream: an all-reduce that ran
+before its arena's last accumulation, or an Adam update that ran before the reduction landed, would change the weights."""
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+
+H = 64
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_steps(force_dp):
+    import torch.distributed as dist
+    from multimodal_segmentation_amd import nn
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from multimodal_segmentation_amd.parallel import dp
+    nn.set_default_device('cuda:0')
+    conf = Hh.make_conf(dafnet_config_chaos, H)
+    model = DAFNet(conf)
+    model.build()
+    dp.enable(force_dp, force=force_dp)
+    assert dp.enabled() == force_dp
+    gens = model._generator_models()
+    if force_dp:
+        dp.sync_model(model)
+    B = 2
+    d = Hh.make_step_data(B, H, H, seed=5)
+    ones = np.ones((B, 1), np.float32)
+    out = {}
+    for it in range(2):
+        model.D_Mask_trainer.fit([d['dm_m1'], d['dm_m2']], [1.0, 0.0])
+        if force_dp:
+            assert dp._state['last_overlapped'] == 0 and dp._state['last_collectives'] == 1
+        h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']],
+                                         [d['m1'], d['m2'], d['m1'], d['m2']] + [ones] * 4 +
+                                         [d['x1'], d['x2'], d['x1'], d['x2']] + [ones] * 4 +
+                                         [np.zeros(B, np.float32)] * 2 + [d['z1'], d['z2']],
+                                         eps=[d['eps1'], d['eps2']])
+        if force_dp:     # every generator arena reduced while the backward pass was still being queued
+            assert dp._state['last_overlapped'] == len(gens) == dp._state['last_collectives'], dp._state
+        out['loss%d' % it] = h.history['loss'][0]
+    torch.cuda.synchronize()
+    out['gen'] = [m.arena.detach().cpu().numpy().copy() for m in gens]
+    out['dm'] = model.D_Mask.arena.detach().cpu().numpy().copy()
+    dp.enable(False)
+    return out
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_step_is_bitwise_the_plain_step():
+    import torch.distributed as dist
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    ref = _run_steps(False)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        assert dist.get_backend() == 'nccl'
+        got = _run_steps(True)
+    finally:
+        dist.destroy_process_group()
+    assert got['loss0'] == ref['loss0'] and got['loss1'] == ref['loss1'], (got['loss0'], ref['loss0'], got['loss1'], ref['loss1'])
+    assert np.array_equal(got['dm'], ref['dm']), 'D_Mask weights differ after two RCCL-reduced steps'
+    for a, b in zip(got['gen'], ref['gen']):
+        assert np.array_equal(a, b), 'generator weights differ after two RCCL-reduced steps'

@@ -55,3 +55,59 @@ def test_experiment_runs_end_to_end(tmp_path, monkeypatch):
     rows = open(os.path.join(folder, 'test_results_chaos_t1_simple', 'results.csv')).read().strip().split('\n')
     assert rows[0] == 'Vol, Dice, Dice0, Dice1, Dice2, Dice3' and len(rows) == 4     # three test volumes
     shutil.rmtree(folder, ignore_errors=True)
+
+
+_COMPAT_SCRIPT = r'''
+import importlib, sys, warnings
+warnings.simplefilter('error', ImportWarning)
+import multimodal_segmentation_amd.compat as compat
+compat.install()
+# what the reference's experiment.py:113-124 does with conf.model / conf.executor
+from configuration import dafnet_config_chaos
+conf = dafnet_config_chaos.get()
+mod, cls = conf['model'].split('.')
+Model = getattr(importlib.import_module('models.' + mod), cls)
+mod, cls = conf['executor'].split('.')
+Exe = getattr(importlib.import_module('model_executors.' + mod), cls)
+# what models/dafnet.py:11-16 and the executors do
+from model_components import anatomy_encoder, anatomy_fuser, balancer, decoder, modality_encoder, segmentor
+from models.discriminator import Discriminator
+from layers import spade, stn_spline
+from loaders import loader_factory
+from callbacks import swa
+from utils import data_utils, distributions
+import costs, model_tester
+import multimodal_segmentation_amd.model_components.decoder as real_decoder
+import multimodal_segmentation_amd.models.dafnet as real_dafnet
+assert decoder is real_decoder and Model is real_dafnet.DAFNet
+assert decoder.__spec__.name == 'multimodal_segmentation_amd.model_components.decoder'
+try:
+    import utils.does_not_exist
+    raise SystemExit('a module the package does not have must stay unimportable')
+except ModuleNotFoundError:
+    pass
+# decoder.build(conf) exactly as the reference calls it (the CPU stand-in replaces the kernels: no GPU here)
+from tests import cpu_backend as cb, helpers as Hh
+cb.install()
+from multimodal_segmentation_amd import nn
+nn.set_default_device('cpu')
+c = Hh.make_conf(dafnet_config_chaos, 32)
+dec = decoder.build(c)
+import numpy as np
+y = dec.predict([np.zeros((1, 32, 32, 8), np.float32), np.zeros((1, 8), np.float32)])
+assert y.shape == (1, 32, 32, 1)
+compat.uninstall()
+assert 'model_components' not in sys.modules
+print('COMPAT-OK')
+'''
+
+
+def test_reference_top_level_module_names_resolve():
+    """SURVEY 8b: callers import `model_components.decoder`, resolve 'models.' + conf.model etc.  Run in a fresh interpreter
+    from the repository root (where `python experiment.py` runs) so that nothing imported by the test session interferes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', _COMPAT_SCRIPT], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=300)
+    assert out.returncode == 0 and b'COMPAT-OK' in out.stdout, out.stderr.decode()[-2000:]

@@ -1,0 +1,74 @@
+"""The three `normalise` modes of the anatomy-encoder UNet (reference utils/model_utils.py:6-12: 'batch' ->
+BatchNormalization, 'instance' -> keras_contrib InstanceNormalization() with its scalar affine, anything else -> identity):
+product (HIP kernels on the GPU; the CPU stand-in under `-m "not gpu"`) vs the fp64 oracle with identical weights -- forward
+(pre-rounding softmax) and the gradient of every weight under a fixed linear functional of the output."""
+import numpy as np
+import pytest
+import torch
+
+from multimodal_segmentation_amd import nn
+from multimodal_segmentation_amd.configuration import mmsdnet_config_chaos
+from multimodal_segmentation_amd.model_components import anatomy_encoder
+from oracle import models as OM
+from tests import helpers as Hh
+
+
+@pytest.fixture(params=[pytest.param('cpu', id='cpu-standin'), pytest.param('cuda', marks=pytest.mark.gpu, id='mi355x')])
+def device(request):
+    if request.param == 'cpu':
+        from tests import cpu_backend as cb
+        cb.install()
+        nn.set_default_device('cpu')
+        yield 'cpu'
+        cb.uninstall()
+    else:
+        assert torch.cuda.is_available()
+        nn.set_default_device('cuda:0')
+        yield 'cuda'
+
+
+@pytest.mark.parametrize('norm', ['instance', None, 'batch'])
+def test_unet_normalise_modes(norm, device):
+    H, B, f = 32, 2, 16
+    conf = Hh.make_conf(mmsdnet_config_chaos, H).anatomy_encoder
+    conf.normalise, conf.filters = norm, f
+    enc = anatomy_encoder.build(conf, 'Enc_Anatomy_t', rng=np.random.RandomState(7))
+    names = [p.name for p in enc.params.values()]
+    if norm == 'instance':
+        assert enc.params['d0a_bn/gamma'].shape == (1,) and 'd0a_bn/moving_mean' not in enc.params
+    elif norm is None:
+        assert not any('_bn/' in n for n in names)
+    else:
+        assert enc.params['d0a_bn/gamma'].shape == (f,) and 'd0a_bn/moving_mean' in enc.params
+    # non-trivial affine parameters
+    rng = np.random.RandomState(1)
+    for p in enc.params.values():
+        if p.trainable and ('gamma' in p.name or 'beta' in p.name or 'bias' in p.name):
+            p.data.copy_(torch.from_numpy((p.data.cpu().numpy() + 0.1 * rng.standard_normal(p.shape)).astype(np.float32)).to(p.data.device))
+    x = Hh.smooth_field(rng, B, H, H)
+    R = rng.standard_normal((B, H, H, 8)).astype(np.float32)
+
+    P = {k: torch.as_tensor(v, dtype=torch.float64) for k, v in enc.named_weights('EA0/').items()}
+    train_names = ['EA0/' + p.name for p in enc.params.values() if p.trainable]
+    for n in train_names:
+        P[n].requires_grad_(True)
+    soft_o = OM.anatomy_encoder_mmsdnet(torch.as_tensor(x, dtype=torch.float64), P, 0, True, [], soft_only=True)
+    (soft_o * torch.as_tensor(R, dtype=torch.float64)).sum().backward()
+
+    enc.zero_grad()
+    with torch.enable_grad():
+        enc(nn.to_device(x, enc.device), training=True)
+        soft_p = enc.last_soft
+        torch.autograd.backward([soft_p], [nn.to_device(R, enc.device)])
+    err = np.abs(soft_p.detach().cpu().numpy() - soft_o.detach().numpy()).max()
+    assert err < 1e-4, 'softmax (normalise=%r): %.3e' % (norm, err)
+    for p in enc.params.values():
+        if not p.trainable:
+            continue
+        if norm == 'batch' and p.name.endswith('/bias') and p.name != 'conv_anatomy/bias':
+            continue          # bias in front of a training-mode BatchNorm: gradient exactly zero, not accumulated
+        g_o = P['EA0/' + p.name].grad.numpy()
+        g_p = p.grad.detach().cpu().numpy()
+        scale = max(np.abs(g_o).max(), 1e-6)
+        rel = np.abs(g_p - g_o).max() / scale
+        assert rel < 2e-3, 'gradient %s (normalise=%r): rel err %.3e (scale %.3e)' % (p.name, norm, rel, scale)
