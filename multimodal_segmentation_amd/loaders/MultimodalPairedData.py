@@ -16,14 +16,18 @@ log = logging.getLogger('MultimodalPairedData')
 
 
 class MultimodalPairedData(Data):
-    def __init__(self, images, masks, index, downsample=1):
+    def __init__(self, images, masks, index, downsample=1, num_modalities=2):
+        """`num_modalities` > 2 is a build-defined extension (BASELINE config #5); the reference splits into two halves
+        (MultimodalPairedData.py:14-22)."""
         super(MultimodalPairedData, self).__init__(images, masks, index, downsample)
         stacked_images, stacked_masks = self.images, self.masks
         del self.images, self.masks                      # per-modality storage from here on, as in the reference
-        self.num_modalities = stacked_images.shape[-1]
-        self.masks_per_mod = k = stacked_masks.shape[-1] // 2
-        self.image_dict = {m: stacked_images[..., m:m + 1] for m in range(2)}
-        self.masks_dict = {m: stacked_masks[..., m * k:(m + 1) * k] for m in range(2)}
+        M = int(num_modalities)
+        assert stacked_images.shape[-1] == M and stacked_masks.shape[-1] % M == 0, (stacked_images.shape, stacked_masks.shape, M)
+        self.num_modalities = M
+        self.masks_per_mod = k = stacked_masks.shape[-1] // M
+        self.image_dict = {m: stacked_images[..., m:m + 1] for m in range(M)}
+        self.masks_dict = {m: stacked_masks[..., m * k:(m + 1) * k] for m in range(M)}
 
     # ---- accessors ---------------------------------------------------------------------------------------------------
     def get_images_modi(self, mod_i):

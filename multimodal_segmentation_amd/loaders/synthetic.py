@@ -28,26 +28,29 @@ def ellipse_masks(rng, H, W, num_masks):
 
 
 class SyntheticPairedData(MultimodalPairedData):
-    """Two modalities of the same synthetic anatomy: modality 2 is a smooth intensity remap of modality 1 plus its
-    own texture, organs are brighter/darker ellipses, so that segmentation is learnable."""
+    """Two (or `num_modalities`) modalities of the same synthetic anatomy: modality 2 is a smooth intensity remap of modality 1
+    plus its own texture, organs are brighter/darker ellipses, so that segmentation is learnable; a third modality (BASELINE
+    config #5, a build-defined extension) shows the organs with alternating sign."""
 
-    def __init__(self, input_shape, num_masks, volumes, slices_per_volume, seed):
+    def __init__(self, input_shape, num_masks, volumes, slices_per_volume, seed, num_modalities=2):
         H, W = input_shape[0], input_shape[1]
         rng = np.random.RandomState(seed)
         n = len(volumes) * slices_per_volume
-        images = np.zeros((n, H, W, 2), np.float32)
-        masks = np.zeros((n, H, W, 2 * num_masks), np.float32)
+        M = int(num_modalities)
+        images = np.zeros((n, H, W, M), np.float32)
+        masks = np.zeros((n, H, W, M * num_masks), np.float32)
         index = np.repeat(np.asarray(volumes), slices_per_volume)
         sigma = max(H / 32.0, 1.0)
         for i in range(n):
             m = ellipse_masks(rng, H, W, num_masks)
             organ = (m * np.linspace(0.4, 1.0, num_masks)[None, None]).sum(-1)
-            for mod in range(2):
+            alt = (m * (np.linspace(0.4, 1.0, num_masks) * np.where(np.arange(num_masks) % 2 == 0, 1.0, -1.0))[None, None]).sum(-1)
+            for mod in range(M):
                 tex = smooth_field(rng, H, W, sigma)
-                img = 0.5 * tex + (organ if mod == 0 else -organ)
+                img = 0.5 * tex + (organ if mod == 0 else (-organ if mod == 1 else alt))
                 images[i, ..., mod] = (img - img.min()) / (img.max() - img.min() + 1e-12) * 2 - 1
                 masks[i, ..., mod * num_masks:(mod + 1) * num_masks] = m
-        super(SyntheticPairedData, self).__init__(images, masks, index)
+        super(SyntheticPairedData, self).__init__(images, masks, index, num_modalities=M)
         self.image_dict = {k: np.ascontiguousarray(v) for k, v in self.image_dict.items()}
         self.masks_dict = {k: np.ascontiguousarray(v) for k, v in self.masks_dict.items()}
 

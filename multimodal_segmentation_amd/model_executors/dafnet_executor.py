@@ -92,7 +92,10 @@ class DAFNetExecutor(Executor):
         from ..parallel import dp
         vols = synthetic.splits()['training']
         return synthetic.SyntheticPairedData(self.conf.input_shape, self.conf.num_masks, vols, slices_per_volume,
-                                             data_seed + dp.rank())
+                                             data_seed + dp.rank(), num_modalities=self._num_mod())
+
+    def _num_mod(self):
+        return len(self.model.modalities)
 
     def _pairing(self, data, seed=None):
         """randomised / automated pairing of the training pairs (dafnet_executor.py:89-93,130-134)"""
@@ -116,8 +119,9 @@ class DAFNetExecutor(Executor):
             self._pairing(self.data, seed=conf.seed)
             self.data_len = self.data.size()
             d = self.data
-            self.gen_labelled = self.get_data_generator(train_images=[d.get_images_modi(i) for i in range(2)],
-                                                        train_labels=[d.get_masks_modi(i) for i in range(2)])
+            nmod = self._num_mod()
+            self.gen_labelled = self.get_data_generator(train_images=[d.get_images_modi(i) for i in range(nmod)],
+                                                        train_labels=[d.get_masks_modi(i) for i in range(nmod)])
         if conf.l_mix < 1:                                   # _init_unlabelled_data_generator / _load_unlabelled_data (101-146)
             u = self.load_training_volumes(slices_per_volume, data_seed)
             conf.num_ul_volumes = u.num_volumes
@@ -129,20 +133,21 @@ class DAFNetExecutor(Executor):
             conf.unlabelled_image_num = u.size()
             if self.data is None or u.size() > self.data.size():
                 self.data_len = u.size()
-            self.gen_unlabelled = self.get_data_generator(train_images=[u.get_images_modi(i) for i in range(2)],
+            self.gen_unlabelled = self.get_data_generator(train_images=[u.get_images_modi(i) for i in range(self._num_mod())],
                                                           train_labels=[u.get_masks_modi(0)])
         self.discriminator_masks = self.get_data_generator(train_labels=[self._load_discriminator_masks()])
         everything = self.load_training_volumes(slices_per_volume, data_seed)    # 'all' data of a modality (141-143,168-171)
-        self.discriminator_image = [self.get_data_generator(train_images=[everything.get_images_modi(m)]) for m in range(2)]
+        self.discriminator_image = [self.get_data_generator(train_images=[everything.get_images_modi(m)])
+                                    for m in range(self._num_mod())]
         self.val_data = synthetic.SyntheticPairedData(conf.input_shape, conf.num_masks, synthetic.splits()['validation'],
-                                                      slices_per_volume, data_seed + 101)
+                                                      slices_per_volume, data_seed + 101, num_modalities=self._num_mod())
         self.batches = int(np.ceil(self.data_len / float(conf.batch_size)))
 
     def _load_discriminator_masks(self):
         """real masks for D_Mask: both modalities of the labelled data + modality 1 of the unlabelled (dafnet_executor.py:148-165)"""
         masks = []
         if self.data is not None:
-            masks.append(np.concatenate([self.data.get_masks_modi(0), self.data.get_masks_modi(1)], axis=0))
+            masks.append(np.concatenate([self.data.get_masks_modi(i) for i in range(self._num_mod())], axis=0))
         if self.ul_data is not None:
             masks.append(self.ul_data.get_masks_modi(0))
         masks = np.concatenate(masks, axis=0)

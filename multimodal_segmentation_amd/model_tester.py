@@ -48,7 +48,8 @@ class ModelTester(object):
         if self.test_data is None:
             vols = synthetic.splits()['test']
             self.test_data = synthetic.SyntheticPairedData(self.conf.input_shape, self.conf.num_masks, vols,
-                                                           self.conf.get('slices_per_volume', 20), 1234 + 202)
+                                                           self.conf.get('slices_per_volume', 20), 1234 + 202,
+                                                           num_modalities=len(self.model.modalities))
         data = self.test_data
         data.crop(self.conf.input_shape[:2])
         return data
@@ -77,7 +78,7 @@ class ModelTester(object):
             raise AssertionError(type)
         rows = []
         for vol in test_data.volumes():
-            pair = [test_data.get_volume_images_modi(m, vol) for m in (0, 1)]
+            pair = [test_data.get_volume_images_modi(m, vol) for m in range(len(self.model.modalities))]
             assert pair[0].shape[0] > 0
             truth = test_data.get_volume_masks_modi(modality_index, vol)
             joint, per_organ = volume_scores(truth, self.model.predict_mask(modality_index, type, pair), self.conf.num_masks)

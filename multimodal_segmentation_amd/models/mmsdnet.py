@@ -3,6 +3,14 @@
 Supervised trainer (mmsdnet.py:146-192): 24 outputs = 6 segmentations (Dice, w_sup_M), 6 adversarial (mse, w_adv_M),
 6 reconstructions (mae, w_rec_X), 6 KL (ypred, w_kl).  z is RE-ENCODED from the deformed / fused anatomies
 (mmsdnet.py:168-172).  Z_Regressor (194-208) is a separate compiled model over 6 (s, z) pairs.
+
+More than two modalities (BASELINE config #5: 3-modality MMSDNet) -- a BUILD-DEFINED EXTENSION, the reference hard-wires
+two (mmsdnet.py:105,120-129,160-161).  The two-modality graph is "every modality by itself, then every ORDERED pair
+(i -> j): deform anatomy i onto j, fuse, segment both against modality j's masks, re-encode z from modality j's image,
+reconstruct modality j" with the pairs (0 -> 1), (1 -> 0).  For M modalities the same recipe runs over all M (M - 1) ordered
+pairs in the order (0,1), (0,2), ..., (1,0), (1,2), ...: n_out = M + 2 M (M - 1) outputs of each of the four kinds (6 for
+M = 2 -- the reference graph exactly; 15 for M = 3).  Unsupervised: masks exist for modality 0 only, so the Dice terms are
+m_0 and the (i -> 0) pairs.  Parity for M > 2 is by construction against the oracle's same extension only.
 """
 import logging
 import os
@@ -62,7 +70,7 @@ class MMSDNet(BaseNet):
 
     # ---- checkpoint: one file for the whole supervised trainer (mmsdnet.py:42-60) --------------------------------
     def _all_component_models(self):
-        return [self.Encoders_Anatomy[0], self.Encoders_Anatomy[1], self.Enc_Modality, self.Anatomy_Fuser, self.Segmentor,
+        return list(self.Encoders_Anatomy) + [self.Enc_Modality, self.Anatomy_Fuser, self.Segmentor,
                 self.Decoder, self.D_Mask]
 
     def load_models(self):
@@ -128,41 +136,69 @@ class MMSDNet(BaseNet):
     def _frozen(self, *models):
         return _Frozen(models)
 
+    # ---- modality pairs ---------------------------------------------------------------------------------------------
+    @property
+    def num_mod(self):
+        return len(self.modalities)
+
+    def pairs(self):
+        """ordered (source -> target) modality pairs in graph order: [(0, 1), (1, 0)] for the reference's two modalities"""
+        M = self.num_mod
+        return [(i, j) for i in range(M) for j in range(M) if i != j]
+
+    def n_out(self):
+        """outputs of each kind: M per-modality + (deformed, fused) per ordered pair (`num_mod * 3` in mmsdnet.py:131-138)"""
+        return self.num_mod + 2 * len(self.pairs())
+
+    def seg_target_modalities(self, supervised):
+        """modality whose masks are the target of every Dice output, in output order (mmsdnet_executor.py:254,284)"""
+        if supervised:
+            return list(range(self.num_mod)) + [j for (_, j) in self.pairs() for _k in range(2)]
+        return [0] + [0 for (_, j) in self.pairs() if j == 0 for _k in range(2)]
+
+    def rec_target_modalities(self):
+        """modality whose image is the target of every reconstruction output (mmsdnet_executor.py:256)"""
+        return list(range(self.num_mod)) + [j for (_, j) in self.pairs() for _k in range(2)]
+
     def _graph(self, supervised):
         nm = self.num_masks
 
         def graph(ins, training=True, eps=None):
             x_list = ins
-            eps = eps or [None] * 6
+            M, pairs, n = self.num_mod, self.pairs(), self.n_out()
+            assert len(x_list) == M, '%d inputs for %d modalities' % (len(x_list), M)
+            eps = eps or [None] * n
             with self._frozen(self.D_Mask):
-                s_list = [self.Encoders_Anatomy[i](x_list[i], training=training) for i in range(2)]
-                z_list = [self.Enc_Modality(s_list[i], x_list[i], eps=eps[i]) for i in range(2)]
-                m1, m2 = [self.Segmentor(s, training=training) for s in s_list]
-                s1_def, s1_fused = self.Anatomy_Fuser(s_list[0], s_list[1])
-                s2_def, s2_fused = self.Anatomy_Fuser(s_list[1], s_list[0])
-                fused_seg = [self.Segmentor(s, training=training) for s in [s1_def, s1_fused, s2_def, s2_fused]]
+                s_list = [self.Encoders_Anatomy[i](x_list[i], training=training) for i in range(M)]
+                z_list = [self.Enc_Modality(s_list[i], x_list[i], eps=eps[i]) for i in range(M)]
+                m_own = [self.Segmentor(s, training=training) for s in s_list]
+                # deform + fuse every ordered pair (mmsdnet.py:120-121,160-161 for the two pairs of two modalities)
+                fused = []
+                for (i, j) in pairs:
+                    fused += self.Anatomy_Fuser(s_list[i], s_list[j])           # [s_i_def, s_i_fused]
+                fused_seg = [self.Segmentor(s, training=training) for s in fused]
                 if supervised:
-                    m_list = [m1, m2] + fused_seg
-                else:
-                    m_list = [m1] + fused_seg[2:]               # masks only for modality 1 (mmsdnet.py:107,116)
-                # the frozen discriminator and the decoder have no batch statistics: six calls each -> one batched call
-                adv_m_list = ops.split_batch(self.D_Mask(ops.cat_batch([ops.slice_channels(m, 0, nm) for m in [m1, m2] + fused_seg])), 6)
-                z_s1def = [self.Enc_Modality(s, x_list[1], eps=eps[2 + i]) for i, s in enumerate([s1_def, s1_fused])]
-                z_s2def = [self.Enc_Modality(s, x_list[0], eps=eps[4 + i]) for i, s in enumerate([s2_def, s2_fused])]
-                rec_x_list = ops.split_batch(self.Decoder(
-                    ops.cat_batch(s_list + [s1_def, s1_fused, s2_def, s2_fused]),
-                    ops.cat_batch([z_list[0][0], z_list[1][0], z_s1def[0][0], z_s1def[1][0], z_s2def[0][0], z_s2def[1][0]])), 6)
-                diverg = [z_list[i][1] for i in range(2)] + [z_s1def[i][1] for i in range(2)] + [z_s2def[i][1] for i in range(2)]
+                    m_list = m_own + fused_seg
+                else:        # masks only for modality 0 (mmsdnet.py:107,116): m_0 and the (i -> 0) pairs
+                    m_list = [m_own[0]] + [fused_seg[2 * p + k] for p, (_, j) in enumerate(pairs) if j == 0 for k in range(2)]
+                # the frozen discriminator and the decoder have no batch statistics: n calls each -> one batched call
+                adv_m_list = ops.split_batch(self.D_Mask(ops.cat_batch([ops.slice_channels(m, 0, nm) for m in m_own + fused_seg])), n)
+                # z re-encoded from the deformed / fused anatomy and the TARGET modality's image (mmsdnet.py:127-131)
+                z_pair = [self.Enc_Modality(s, x_list[pairs[q // 2][1]], eps=eps[M + q]) for q, s in enumerate(fused)]
+                rec_x_list = ops.split_batch(self.Decoder(ops.cat_batch(s_list + fused),
+                                                          ops.cat_batch([z[0] for z in z_list + z_pair])), n)
+                diverg = [z[1] for z in z_list + z_pair]
             return m_list + adv_m_list + rec_x_list + diverg
         return graph
 
     def _specs(self, supervised):
         c = self.conf
-        n_seg = 6 if supervised else 3
+        n = self.n_out()
+        n_seg = len(self.seg_target_modalities(supervised))
         return [OutputSpec('Segmentor', costs.make_dice_loss_fnc(self.num_masks), c.w_sup_M) for _ in range(n_seg)] + \
-               [OutputSpec('D_Mask', 'mse', c.w_adv_M) for _ in range(6)] + \
-               [OutputSpec('Decoder', 'mae', c.w_rec_X) for _ in range(6)] + \
-               [OutputSpec('Enc_Modality', costs.ypred, c.w_kl) for _ in range(6)]
+               [OutputSpec('D_Mask', 'mse', c.w_adv_M) for _ in range(n)] + \
+               [OutputSpec('Decoder', 'mae', c.w_rec_X) for _ in range(n)] + \
+               [OutputSpec('Enc_Modality', costs.ypred, c.w_kl) for _ in range(n)]
 
     def build_unsupervised_trainer(self):
         self.unsupervised_trainer = Trainer('unsupervised_trainer', self._graph(False), self._specs(False),
@@ -183,13 +219,14 @@ class MMSDNet(BaseNet):
         return Trainer('ZReconstruct', graph, specs, [self.Decoder, self.Enc_Modality], nn.Adam(self.conf.lr))
 
     def build_z_regressor(self):
-        self.Z_Regressor = self._z_regressor(len(self.modalities) + 4)      # mmsdnet.py:194-208
+        self.Z_Regressor = self._z_regressor(self.n_out())      # len(modalities) + 4 = 6 in mmsdnet.py:194-208
 
-    def predict_mask(self, modality_index, type, image_list):
-        """reference mmsdnet.py:210-232"""
+    def predict_mask(self, modality_index, type, image_list, source_index=None):
+        """reference mmsdnet.py:210-232.  `source_index` (more than two modalities only): the modality deformed onto
+        `modality_index`; default = the reference's `1 - modality_index` for modalities 0 / 1, modality 0 otherwise."""
         assert type in ['simple', 'def', 'max', 'maxnostn']
         idx2 = modality_index
-        idx1 = 1 - idx2
+        idx1 = (1 - idx2 if idx2 in (0, 1) else 0) if source_index is None else source_index
         images_mod1 = image_list[idx1]
         images_mod2 = image_list[idx2]
         s1 = self.Encoders_Anatomy[idx1].predict(images_mod1)

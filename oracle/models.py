@@ -410,10 +410,10 @@ def build_dafnet_params(seed, H, W, decoder_type='film', f=64, d_filters=64, num
     return pb.P
 
 
-def build_mmsdnet_params(seed, H, W, decoder_type='film', f=64, d_filters=4, num_masks=4, dtype=torch.float32):
+def build_mmsdnet_params(seed, H, W, decoder_type='film', f=64, d_filters=4, num_masks=4, dtype=torch.float32, num_mod=2):
     pb = ParamBuilder(seed, dtype)
     build_discriminator(pb, 'DM/', H, W, num_masks, d_filters)
-    for m in range(2):
+    for m in range(num_mod):
         build_unet_down(pb, 'EA%d/' % m, 1, f)
         build_unet_up(pb, 'EA%d/' % m, f, 8)
     build_fuser(pb, H, W)

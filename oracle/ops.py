@@ -20,6 +20,24 @@ LRELU_DEFAULT = 0.3  # keras.layers.LeakyReLU() default alpha (dd)
 # ----------------------------------------------------------------------------
 # convolution / dense (Keras Conv2D, Dense; weights in Keras layout)
 # ----------------------------------------------------------------------------
+_OPERAND_ROUNDING = [None]
+
+
+def set_conv_operand_rounding(dtype):
+    """None (default) | torch.bfloat16 | torch.float16: emulate the product's reduced-precision compute modes (BASELINE
+    configs #3 / #5; NOT a reference behaviour -- the reference is fp32 throughout).  In those modes the product's MFMA
+    convolutions (input channels a multiple of 32, output channels a multiple of 4) multiply operands ROUNDED to the 16-bit
+    type and accumulate in fp32; every other operation stays fp32.  With the rounding emulated here the products are exact in
+    both implementations and only the accumulation order differs.  Returns the previous setting."""
+    old = _OPERAND_ROUNDING[0]
+    _OPERAND_ROUNDING[0] = dtype
+    return old
+
+
+def _round_operand(t):
+    return t.to(_OPERAND_ROUNDING[0]).to(t.dtype)
+
+
 def conv2d(x, w, b=None, stride=1, padding='same'):
     """Keras Conv2D on NHWC input with HWIO kernel.
 
@@ -34,6 +52,8 @@ def conv2d(x, w, b=None, stride=1, padding='same'):
         pad = (kh // 2, kw // 2)
     else:
         pad = (0, 0)
+    if _OPERAND_ROUNDING[0] is not None and w.shape[2] % 32 == 0 and w.shape[3] % 4 == 0:
+        x, w = _round_operand(x), _round_operand(w)
     y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, stride=stride, padding=pad)
     return y.permute(0, 2, 3, 1)
 

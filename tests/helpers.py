@@ -115,7 +115,7 @@ def product_grads(model):
 
 
 def _mmsdnet_items(model):
-    return [('DM/', model.D_Mask), ('EA0/', model.Encoders_Anatomy[0]), ('EA1/', model.Encoders_Anatomy[1]),
+    return [('DM/', model.D_Mask)] + [('EA%d/' % i, e) for i, e in enumerate(model.Encoders_Anatomy)] + [
             ('FUS/', model.Anatomy_Fuser), ('EM/', model.Enc_Modality), ('SEG/', model.Segmentor), ('DEC/', model.Decoder)]
 
 

@@ -194,7 +194,7 @@ def test_the_ctypes_stub_of_INTEGRATION_md_runs():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     text = open(os.path.join(root, 'INTEGRATION.md')).read()
-    code = re.search(r"```python\n(.*?)```", text, flags=re.S).group(1)
+    code = [c for c in re.findall(r"```python\n(.*?)```", text, flags=re.S) if 'ctypes.CDLL' in c][0]
     ns = {}
     cwd = os.getcwd()
     os.chdir(root)                     # the snippet loads the library by its in-tree relative path
@@ -208,3 +208,99 @@ def test_the_ctypes_stub_of_INTEGRATION_md_runs():
     y = ns['conv3x3_same_relu'](x, w, b)
     ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, padding=1)).permute(0, 2, 3, 1)
     assert float((y - ref).abs().max()) < 1e-4
+
+
+# ---- BASELINE.json configurations at their own sizes --------------------------------------------------------------------
+def test_config2_generator_step_at_256_bs8_against_the_oracle():
+    """BASELINE config #2 at its own size: one teacher-forced DAFNet-FiLM supervised generator step at 256 x 256, batch 8 -- all 20
+    outputs, label maps, every loss term, BatchNorm moving statistics, gradients and post-Adam weights vs the oracle (run in
+    fp32 here: the fp64 run needs > 60 GB; tolerances as in test_dafnet_step.py, gradients against a fixed bar because the fp32
+    oracle IS the noise floor)."""
+    from tests.test_dafnet_step import _generator_step_check
+    _generator_step_check('film', H, True, 'cuda', B=B, oracle_dtype=torch.float32, out_tol=1e-3, grad_floor=0.15)
+
+
+def _fixed_batch_property_run(model, conf, d, n_iter=3):
+    """generator-only iterations on one fixed batch: finite, decreasing total; then the same step twice from the same state is
+    bit-identical"""
+    gens = model._generator_models()
+    tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [1.0] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [1.0] * 4 + [0.0] * 2 + [d['z1'], d['z2']]
+    rec = []
+    for _ in range(n_iter):
+        h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']])
+        vals = {k: h.history[k][0] for k in h.history.keys()}
+        assert all(np.isfinite(v) for v in vals.values()), vals
+        rec.append(vals['loss'])
+    assert rec[-1] < rec[0], rec
+    g0 = [m.get_weights() for m in gens]
+    steps = []
+    for _ in range(2):
+        for m, w in zip(gens, g0):
+            m.set_weights(w)
+        model.supervised_trainer.optimizer = nn.Adam(conf.lr)
+        model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']])
+        steps.append([m.grad_arena.clone() for m in gens] + [m.arena.clone() for m in gens])
+    for a, b in zip(*steps):
+        assert torch.equal(a, b)
+
+
+def test_config3_spade_bf16_at_256_bs8_properties():
+    """BASELINE config #3's model, size, batch and dtype (DAFNet-SPADE, 256 x 256, batch 8, bf16 MFMA operands): full
+    iterations of the executor's schedule stay finite, a fixed batch is learnt, and the step is bitwise reproducible.  (Parity
+    against the oracle for this configuration: tests/test_dafnet_step.py::test_generator_step_reduced_precision... at 64 x 64.)"""
+    from multimodal_segmentation_amd.configuration import dafnet_spade_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    conf = Hh.make_conf(dafnet_spade_config_chaos, H, batch_size=B, compute_dtype='bf16')
+    try:
+        model = DAFNet(conf)
+        model.build()
+        assert P.set_conv_precision('bf16') == 'bf16'
+        ex = DAFNetExecutor(conf, model)
+        ex.init_train_data(slices_per_volume=4)
+        losses = {n: [] for n in ex.get_loss_names()}
+        for _ in range(2):
+            ex.train_batch(losses)
+        for k in ('supervised_Mask', 'adv_M', 'rec_X', 'adv_X1', 'adv_X2', 'KL', 'rec_Z', 'dis_M', 'dis_X1', 'dis_X2'):
+            assert len(losses[k]) >= 2 and all(np.isfinite(float(v)) for v in losses[k]), (k, losses[k])
+        _fixed_batch_property_run(model, conf, Hh.make_step_data(B, H, H, seed=23))
+    finally:
+        P.set_conv_precision('fp32')
+
+
+def test_config5_mmsdnet_three_modalities_fp16_at_320_bs16_properties():
+    """BASELINE config #5's model, size, batch and dtype (3-modality MMSDNet -- the build-defined all-ordered-pairs extension --
+    320 x 320, batch 16, fp16 MFMA operands with the static loss scale, fp32 master weights / gradients): full iterations of the
+    executor's schedule stay finite, the fixed-batch generator objective decreases, gradients are finite (no fp16 overflow)."""
+    from multimodal_segmentation_amd.configuration import mmsdnet3_config_chaos
+    from multimodal_segmentation_amd.models.mmsdnet import MMSDNet
+    from multimodal_segmentation_amd.model_executors.mmsdnet_executor import MMSDNetExecutor
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    S, Bb = 320, 16
+    conf = Hh.make_conf(mmsdnet3_config_chaos, S, batch_size=Bb, compute_dtype='fp16')
+    try:
+        model = MMSDNet(conf)
+        model.build()
+        assert model.num_mod == 3 and model.n_out() == 15 and model.supervised_trainer.loss_scale == 1024.0
+        ex = MMSDNetExecutor(conf, model)
+        ex.init_train_data(slices_per_volume=8)
+        losses = {n: [] for n in ex.get_loss_names()}
+        ex.train_batch(losses)
+        ex.train_batch(losses)
+        for k in ('supervised_Mask', 'adv_M', 'rec_X', 'KL', 'rec_Z', 'dis_M'):
+            assert len(losses[k]) == 2 and all(np.isfinite(float(v)) for v in losses[k]), (k, losses[k])
+        for m in model._generator_models():
+            assert bool(torch.isfinite(m.grad_arena).all()), m.name
+        # fixed batch: the weighted generator objective decreases
+        batch = next(ex.gen_labelled)
+        x_list = [b for b in batch[:3]]
+        m_list = [ex._five(b) for b in batch[3:]]
+        tg = ex.generator_targets(x_list, m_list, True)
+        eps = [np.random.RandomState(5 + i).standard_normal((Bb, 8)).astype(np.float32) for i in range(15)]
+        rec = [model.supervised_trainer.fit(x_list, tg, eps=eps).history['loss'][0] for _ in range(3)]
+        assert all(np.isfinite(v) for v in rec) and rec[-1] < rec[0], rec
+    finally:
+        P.set_conv_precision('fp32')

@@ -96,13 +96,15 @@ def test_train_two_epochs_then_test_writes_reference_layout():
 
 
 @pytest.mark.gpu
-def test_mmsdnet_train_epoch_then_test():
+@pytest.mark.parametrize('nmod', [2, 3])
+def test_mmsdnet_train_epoch_then_test(nmod):
     nn.set_default_device('cuda:0')
-    from multimodal_segmentation_amd.configuration import mmsdnet_config_chaos
+    from multimodal_segmentation_amd.configuration import mmsdnet_config_chaos, mmsdnet3_config_chaos
     from multimodal_segmentation_amd.models.mmsdnet import MMSDNet
     from multimodal_segmentation_amd.model_executors.mmsdnet_executor import MMSDNetExecutor
-    conf = Hh.make_conf(mmsdnet_config_chaos, 64, batch_size=4, epochs=1, slices_per_volume=2, test_dataset='chaos')
-    conf.folder = '/tmp/mmseg_test_train_loop_mmsdnet'
+    conf = Hh.make_conf(mmsdnet_config_chaos if nmod == 2 else mmsdnet3_config_chaos, 64, batch_size=4, epochs=1,
+                        slices_per_volume=2, test_dataset='chaos')
+    conf.folder = '/tmp/mmseg_test_train_loop_mmsdnet%d' % nmod
     shutil.rmtree(conf.folder, ignore_errors=True)
     model = MMSDNet(conf)
     model.build()
@@ -112,10 +114,14 @@ def test_mmsdnet_train_epoch_then_test():
         if k == 'loss':       # listed by the reference (mmsdnet_executor.py:26-27) but never recorded there either -> nan
             continue
         assert len(total[k]) == 1 and np.isfinite(total[k][0]), (k, total[k])
-    for f in ('D_Mask', 'Enc_Anatomy1', 'Enc_Anatomy2', 'Enc_Modality', 'Anatomy_Fuser', 'Segmentor', 'Decoder'):
-        assert os.path.exists(conf.folder + '/models/' + f), f
+    # the reference's MMSDNet keeps ONE checkpoint file for the whole supervised trainer (models/mmsdnet.py:42-60), no SWA
+    assert os.path.exists(conf.folder + '/supervised_trainer')
     res = ex.test()
-    assert len(res) == 12 and all(0.0 <= v <= 1.0 for v in res.values())
+    assert len(res) == 6 * nmod and all(0.0 <= v <= 1.0 for v in res.values())     # modalities x 3 fusion modes x 2 pairings
+    model2 = MMSDNet(conf)
+    model2.build()                     # loads <folder>/supervised_trainer
+    for a, b in zip(model2.Segmentor.get_weights(), model.Segmentor.get_weights()):
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.gpu
