@@ -215,6 +215,8 @@ def main():
     ap.add_argument('--decoder', default='film', choices=['film', 'spade'])
     ap.add_argument('--model', default='dafnet', choices=['dafnet', 'mmsdnet'],
                     help="mmsdnet: the MMSDNet iteration (mmsdnet_executor.py:238-331) instead of the headline DAFNet one")
+    ap.add_argument('--modalities', type=int, default=2, choices=[2, 3],
+                    help='3 (with --model mmsdnet): the build-defined 3-modality MMSDNet of BASELINE config #5')
     ap.add_argument('--l_mix', type=float, default=1.0)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f16'],
                     help='bf16: bf16 MFMA operands (fp32 accumulation, fp32 tensors in HBM, fp32 weight gradients) -- configs #3/#5')
@@ -256,8 +258,8 @@ def main():
     _native.load()
     nn.set_default_device('cuda:%d' % local_rank)
     if args.model == 'mmsdnet':
-        from multimodal_segmentation_amd.configuration import mmsdnet_config_chaos
-        cfg = mmsdnet_config_chaos.get()
+        from multimodal_segmentation_amd.configuration import mmsdnet_config_chaos, mmsdnet3_config_chaos
+        cfg = (mmsdnet3_config_chaos if args.modalities == 3 else mmsdnet_config_chaos).get()
     else:
         cfg = (dafnet_config_chaos if args.decoder == 'film' else dafnet_spade_config_chaos).get()
     H = args.size
@@ -345,10 +347,12 @@ def main():
                    'global_batch': world * args.batch, 'parallelism': 'dp%d' % world},
     }
     if args.model == 'mmsdnet':
-        line['config']['workload'] = ('MMSDNet (mmsdnet_config_chaos) %dx%d 2-modality training iteration: generator fit + '
+        line['config']['workload'] = ('MMSDNet (mmsdnet%s_config_chaos) %dx%d %d-modality training iteration: generator fit + '
                                       'Z-regressor fit + mask-D fit incl. the fake pool, bs=%d/GPU, %s, l_mix=%g'
-                                      % (H, H, args.batch, DTYPE_NAME[args.dtype], args.l_mix))
-    key = (args.decoder if args.model == 'dafnet' else 'mmsdnet', H)
+                                      % ('3' if args.modalities == 3 else '', H, H, args.modalities, args.batch,
+                                         DTYPE_NAME[args.dtype], args.l_mix))
+        line['metric'] = line['metric'].replace('x2-modality', 'x%d-modality' % args.modalities)
+    key = (args.decoder if args.model == 'dafnet' else ('mmsdnet' if args.modalities == 2 else 'mmsdnet3'), H)
     if key in TFLOP_PER_PAIR:
         line['conv_tflops_whole_step'] = TFLOP_PER_PAIR[key] * value / world
         line['conv_roofline_frac_whole_step'] = TFLOP_PER_PAIR[key] * value / world / FP32_MFMA_PEAK_TFLOPS
