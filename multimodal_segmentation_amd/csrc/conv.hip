@@ -20,6 +20,7 @@
 // ds_read_b128 feeds four consecutive MFMAs; A and B use the same permutation so the sum is
 // unchanged.
 #include "common.hpp"
+#include <stdio.h>
 #include <stdlib.h>
 
 struct ConvParams {
@@ -1171,6 +1172,260 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_fast_kernel(WgradPara
     }
 }
 
+// =====================================================================================
+// Weight gradient, transposed-staging variant (the layers that carry the FLOPs: stride 1, output width a multiple of 4, channel
+// counts multiples of 4).  Same GEMM as conv_wgrad_fast_kernel (dW[k, n] = sum over pixels of A[p, k] * dy[p, n]) but the LDS
+// tiles are laid out like the forward kernel's -- one row per GEMM row / column holding 32 consecutive PIXELS (the reduction
+// index), 16-byte chunks XOR-swizzled -- so an MFMA operand is one conflict-free ds_read_b128 feeding four MFMAs instead of
+// four ds_read_b32.  The transposition [pixel][channel] (HBM) -> [channel][pixel] (LDS) costs nothing: a thread fetches a
+// 4-pixel x 4-channel block with four 16-byte buffer loads and stores its four channel rows with four 16-byte LDS writes (the
+// register "transpose" is a renaming).  A 32-pixel stage carries 64 MFMAs per wave, twice the old kernel's, and the kernel
+// runs at the forward kernel's occupancy (2-3 blocks per CU) -- which is what lets the host split the pixels into far fewer
+// slabs (mmseg_conv2d_wgrad picks the split from a small cost model): the slab write + re-read, 2.2x the algorithmic HBM
+// bytes in round 1, shrinks accordingly.  Deterministic as before: fixed-order slab reduction, no float atomics.
+// =====================================================================================
+// LDS chunk swizzle of the fp32 tiles: conflict-free for the MFMA operand reads (32 consecutive rows, one chunk) AND for the
+// transposing stores (8 lanes = rows 4 apart, one chunk)
+__device__ __forceinline__ int wg_swz(int row) { return ((row >> 1) ^ (row >> 4)) & 7; }
+
+template <int BKT, int BNT, int WM, int WN, int PREC = 0, bool TWO = false>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams q) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BKT / WM / 32, TN = BNT / WN / 32;
+    constexpr int PT = 32;                               // pixels per LDS stage = K depth of one tile pair
+    constexpr bool LP = PREC != 0;
+    typedef typename LowPrec<PREC>::T LT;
+    typedef typename LowPrec<PREC>::V4 LV4;
+    typedef typename LowPrec<PREC>::V8 LV8;
+    constexpr int LD = LP ? PT / 2 : PT;                 // 4-byte words per LDS row
+    constexpr int A_SZ = BKT * LD, D_SZ = BNT * LD;
+    constexpr int A_PAIRS = (BKT / 4) * (PT / 4), D_PAIRS = (BNT / 4) * (PT / 4);   // (channel quad, pixel group) blocks
+    constexpr int A_IT = (A_PAIRS + NT - 1) / NT, D_IT = (D_PAIRS + NT - 1) / NT;
+    const ConvParams& p = q.c;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + D_SZ)];
+    float* Ap = smem;
+    float* Dp = smem + 2 * A_SZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nkb = (p.K + BKT - 1) / BKT, nnb = (p.Cout + BNT - 1) / BNT;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);     // the tiles of one pixel chunk are consecutive -> one XCD's L2
+    const int bz = lb / (nkb * nnb), brem = lb - bz * (nkb * nnb);
+    const int k0 = (brem % nkb) * BKT, n0 = (brem / nkb) * BNT;
+    const int pbeg = bz * q.chunk;                       // multiple of 32
+    const int pend = min(p.M, pbeg + q.chunk);
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(TWO ? p.x2 : p.x1), 0,
+                                                                        TWO ? p.B * p.H * p.W * p.C2 * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)q.dy, 0, p.M * p.Cout * 4, 0x00020000);
+
+    // ---- A side: this thread's (k quad, pixel group) blocks.  Tap, channel and source tensor are fixed per thread, so the
+    // gather offset is  b * sb + (hi >> sh) * sr + (wi >> sh) * sp + c  with per-thread strides -- no branches in the loop ----
+    const int Cin = p.C1 + p.C2;
+    const int HoWo = p.Ho * p.Wo;
+    const int q32 = PT / p.Wo, r32 = PT - q32 * p.Wo;    // a stage advances the pixel by 32 = q32 rows + r32 columns
+    int a_row[A_IT], a_pg[A_IT], a_dh[A_IT], a_dw[A_IT], a_c[A_IT], a_sb[A_IT], a_sr[A_IT], a_sp[A_IT], a_sh[A_IT];
+    int a_b[A_IT], a_ho[A_IT], a_wo[A_IT];
+    bool a_ok[A_IT], a_from1[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int pair = tid + it * NT;
+        const int cq = pair % (BKT / 4), pg = pair / (BKT / 4);
+        const int k = k0 + 4 * cq;
+        a_ok[it] = pair < A_PAIRS && k < p.K;
+        const int tap = a_ok[it] ? k / Cin : 0, c = a_ok[it] ? k - tap * Cin : 0;
+        a_row[it] = 4 * cq; a_pg[it] = pg;
+        const int kh = tap / p.KW;
+        a_dh[it] = kh - p.pad_h; a_dw[it] = tap - kh * p.KW - p.pad_w;
+        const bool f1 = !TWO || c < p.C1;
+        a_from1[it] = f1;
+        a_c[it] = f1 ? c : c - p.C1;
+        a_sp[it] = f1 ? p.C1 : p.C2;
+        a_sr[it] = f1 ? p.W1 * p.C1 : p.W * p.C2;
+        a_sb[it] = f1 ? p.H1 * p.W1 * p.C1 : p.H * p.W * p.C2;
+        a_sh[it] = f1 ? p.ups : 0;
+        const int m = pbeg + 4 * pg;                     // first of the 4 consecutive pixels (same output row: Wo % 4 == 0)
+        const int b = m / HoWo, r = m - b * HoWo;
+        a_b[it] = b; a_ho[it] = r / p.Wo; a_wo[it] = r - a_ho[it] * p.Wo;
+    }
+    int d_row[D_IT], d_pg[D_IT], d_off[D_IT];
+    bool d_ok[D_IT];
+#pragma unroll
+    for (int it = 0; it < D_IT; ++it) {
+        const int pair = tid + it * NT;
+        const int cq = pair % (BNT / 4), pg = pair / (BNT / 4);
+        d_row[it] = 4 * cq; d_pg[it] = pg;
+        d_ok[it] = pair < D_PAIRS && n0 + 4 * cq < p.Cout;
+        d_off[it] = (pbeg + 4 * pg) * p.Cout + n0 + 4 * cq;
+    }
+
+    f32x4 ra[A_IT][4], rdv[D_IT][4];
+    auto load_stage = [&](int ps) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int hi = a_ho[it] * p.stride + a_dh[it];
+            const bool rowok = a_ok[it] && (unsigned)hi < (unsigned)p.H && ps + 4 * a_pg[it] < pend;
+            const int wi0 = a_wo[it] * p.stride + a_dw[it];
+            const int rowoff = a_b[it] * a_sb[it] + (hi >> a_sh[it]) * a_sr[it] + a_c[it];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int wi = wi0 + j * p.stride;
+                const bool ok = rowok && (unsigned)wi < (unsigned)p.W;
+                const int off = (rowoff + (wi >> a_sh[it]) * a_sp[it]) * 4;
+                // descriptors stay wave-uniform: with two inputs both loads are issued, the unselected one out of range (zeros)
+                if constexpr (!TWO) ra[it][j] = buf_load4(r1, ok ? off : BUF_OOB);
+                else ra[it][j] = buf_load4(r1, (ok && a_from1[it]) ? off : BUF_OOB) + buf_load4(r2, (ok && !a_from1[it]) ? off : BUF_OOB);
+            }
+            // advance the pixel group by one stage (32 pixels): q32 rows + r32 columns, one carry; the host guarantees Ho > q32
+            a_wo[it] += r32; a_ho[it] += q32;
+            if (a_wo[it] >= p.Wo) { a_wo[it] -= p.Wo; ++a_ho[it]; }
+            if (a_ho[it] >= p.Ho) { a_ho[it] -= p.Ho; ++a_b[it]; }
+        }
+#pragma unroll
+        for (int it = 0; it < D_IT; ++it) {
+            const int m0 = ps + 4 * d_pg[it];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                rdv[it][j] = buf_load4(rd, (d_ok[it] && m0 + j < pend) ? (d_off[it] + j * p.Cout) * 4 : BUF_OOB);
+            d_off[it] += PT * p.Cout;
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float* A = Ap + buf * A_SZ;
+        float* D = Dp + buf * D_SZ;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            if (A_PAIRS % NT != 0 && tid + it * NT >= A_PAIRS) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = a_row[it] + e;
+                if constexpr (LP) {
+                    LV4 v = {(LT)ra[it][0][e], (LT)ra[it][1][e], (LT)ra[it][2][e], (LT)ra[it][3][e]};
+                    *reinterpret_cast<LV4*>(&A[row * LD + 4 * ((a_pg[it] >> 1) ^ ((row >> 1) & 3)) + 2 * (a_pg[it] & 1)]) = v;
+                } else {
+                    const f32x4 v = {ra[it][0][e], ra[it][1][e], ra[it][2][e], ra[it][3][e]};
+                    *reinterpret_cast<f32x4*>(&A[row * LD + 4 * (a_pg[it] ^ wg_swz(row))]) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < D_IT; ++it) {
+            if (D_PAIRS % NT != 0 && tid + it * NT >= D_PAIRS) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = d_row[it] + e;
+                if constexpr (LP) {
+                    LV4 v = {(LT)rdv[it][0][e], (LT)rdv[it][1][e], (LT)rdv[it][2][e], (LT)rdv[it][3][e]};
+                    *reinterpret_cast<LV4*>(&D[row * LD + 4 * ((d_pg[it] >> 1) ^ ((row >> 1) & 3)) + 2 * (d_pg[it] & 1)]) = v;
+                } else {
+                    const f32x4 v = {rdv[it][0][e], rdv[it][1][e], rdv[it][2][e], rdv[it][3][e]};
+                    *reinterpret_cast<f32x4*>(&D[row * LD + 4 * (d_pg[it] ^ wg_swz(row))]) = v;
+                }
+            }
+        }
+    };
+
+    constexpr int NACC = (TM * TN >= 4) ? 1 : 4 / (TM * TN);
+    f32x16 acc[NACC][TM][TN];
+#pragma unroll
+    for (int s = 0; s < NACC; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][i][j][r] = 0.f;
+
+    if (pbeg < pend) {
+        load_stage(pbeg);
+        store_stage(0);
+        __syncthreads();
+        const int ar = wm * (BKT / WM) + li, br = wn * (BNT / WN) + li;
+        int cur = 0;
+        for (int ps = pbeg; ps < pend; ps += PT) {
+            const bool more = ps + PT < pend;
+            if (more) load_stage(ps + PT);               // buffer loads in flight under the MFMAs
+            const float* A = Ap + cur * A_SZ;
+            const float* D = Dp + cur * D_SZ;
+            if constexpr (LP) {
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {         // two steps of 16 pixels; lane half lh supplies pixels 16 qq + 8 lh + [0, 8)
+                    LV8 a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        a[i] = *reinterpret_cast<const LV8*>(&A[(ar + i * 32) * LD + 4 * ((2 * qq + lh) ^ (((ar + i * 32) >> 1) & 3))]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        b[j] = *reinterpret_cast<const LV8*>(&D[(br + j * 32) * LD + 4 * ((2 * qq + lh) ^ (((br + j * 32) >> 1) & 3))]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[qq % NACC][i][j] = LowPrec<PREC>::mfma(a[i], b[j], acc[qq % NACC][i][j]);
+                }
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {         // lane half lh supplies pixels 8 qq + 4 lh + [0, 4)
+                    f32x4 a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        a[i] = *reinterpret_cast<const f32x4*>(&A[(ar + i * 32) * LD + 4 * ((2 * qq + lh) ^ wg_swz(ar + i * 32))]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        b[j] = *reinterpret_cast<const f32x4*>(&D[(br + j * 32) * LD + 4 * ((2 * qq + lh) ^ wg_swz(br + j * 32))]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[t % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[t % NACC][i][j], 0, 0, 0);
+                }
+            }
+            if (more) store_stage(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < NACC; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[0][i][j] += acc[s][i][j];
+
+    float* out = q.ws + (size_t)bz * p.K * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BNT / WN) + j * 32 + li;
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * (BKT / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < p.K) out[(size_t)k * p.Cout + n] = acc[0][i][j][r];
+            }
+    }
+}
+
+template <int BKT, int BNT, int WM, int WN, bool TWO>
+static void launch_wgrad_tr_prec(const WgradParams& q, dim3 grid, dim3 block, hipStream_t st) {
+    if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<BKT, BNT, WM, WN, 1, TWO>), grid, block, 0, st, q);
+    else if (g_conv_bf16 == 2) hipLaunchKernelGGL((conv_wgrad_tr_kernel<BKT, BNT, WM, WN, 2, TWO>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_wgrad_tr_kernel<BKT, BNT, WM, WN, 0, TWO>), grid, block, 0, st, q);
+}
+template <int BKT, int BNT, int WM, int WN>
+static int launch_wgrad_tr(const WgradParams& q, int S, hipStream_t st) {
+    dim3 grid(((q.c.K + BKT - 1) / BKT) * ((q.c.Cout + BNT - 1) / BNT) * S), block(WM * WN * 64);
+    if (q.c.C2 > 0) launch_wgrad_tr_prec<BKT, BNT, WM, WN, true>(q, grid, block, st);
+    else launch_wgrad_tr_prec<BKT, BNT, WM, WN, false>(q, grid, block, st);
+    return MMSEG_CHECK_LAUNCH();
+}
+
 template <int BKT, int BNT, int WM, int WN>
 static int launch_wgrad_fast(const WgradParams& q, int S, hipStream_t st) {
     dim3 grid(((q.c.K + BKT - 1) / BKT) * ((q.c.Cout + BNT - 1) / BNT) * S), block(WM * WN * 64);
@@ -1389,11 +1644,62 @@ static int wgrad_splits(long M, long K, int Cout) {
     if (S < 1) S = 1;
     return (int)S;
 }
+// ---- pixel split of the transposed-staging kernel (conv_wgrad_tr_kernel) ----------------------------------------------
+// Fewer, longer blocks: pick the number of slabs S that minimises a small cost model -- rounds of resident blocks (2-4 per
+// CU by tile, the last round possibly partial and then slower per block) plus the slab write + re-read at HBM speed.
+static int wgrad_tr_bnt(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+static int wgrad_tr_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MMSEG_WGRAD_TR"); v = e ? atoi(e) : 1; }
+    return v;
+}
+// K tile: 192 rows (3 taps of 64 channels) when that divides K exactly and 128 does not -- the 64-channel 3x3 layers (K = 576),
+// which would otherwise pad K by 11 %
+static int wgrad_tr_bkt(long K, int Cout) { return (K % 128 != 0 && K % 192 == 0 && Cout > 32) ? 192 : 128; }
+static int wgrad_tr_splits(long M, long K, int Cout, int* chunk_out) {
+    const int bnt = wgrad_tr_bnt(Cout), bkt = wgrad_tr_bkt(K, Cout);
+    const int bpc = bkt == 192 ? 2 : (bnt == 128 ? 2 : (bnt == 64 ? 3 : 4));   // resident blocks per CU (LDS 80 or 64 / 64 / 48 / 40 KB)
+    const long tiles = ((K + bkt - 1) / bkt) * ((Cout + bnt - 1) / bnt);
+    const double cu_rate = 4.0 * 64.0 * 2.4e9;                         // FLOP/s of one CU's fp32 MFMA pipes
+    static const double eff[5] = {0.0, 0.55, 0.75, 0.82, 0.85};       // MFMA efficiency by resident blocks per CU (measured shape)
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("MMSEG_WGRAD_TR_S"); forced = e ? atoi(e) : -1; }
+    long maxS = M / 128;
+    if (maxS < 1) maxS = 1;
+    if (maxS > 4096) maxS = 4096;
+    double best = 1e30; long bestS = 1, bestChunk = (M + 31) / 32 * 32;
+    for (long S = 1; S <= maxS; ++S) {
+        long chunk = ((M + S - 1) / S + 31) / 32 * 32;
+        const long Se = (M + chunk - 1) / chunk;
+        if (Se != S && forced <= 0) continue;                          // same plan as a smaller S: already priced
+        const long blocks = tiles * Se, slots = 256L * bpc;
+        const long full = blocks / slots, rem = blocks % slots;
+        const double blk_flop = (double)chunk * bkt * bnt * 2.0;
+        double t = full * (blk_flop * bpc / (cu_rate * eff[bpc]) + 3e-6);
+        if (rem) { const int r = (int)((rem + 255) / 256); t += blk_flop * r / (cu_rate * eff[r]) + 3e-6; }
+        t += (double)Se * K * Cout * 8.0 / 4.5e12 + 2e-6;              // slab write + re-read, reduce launch
+        if (forced > 0 ? S == forced : t < best) { best = t; bestS = Se; bestChunk = chunk; if (forced > 0) break; }
+    }
+    if (chunk_out) *chunk_out = (int)bestChunk;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("MMSEG_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg && chunk_out)
+        fprintf(stderr, "[wgrad_tr] M=%ld K=%ld N=%d tiles=%ld bpc=%d -> S=%ld chunk=%ld blocks=%ld model=%.1f us\n", M, K, Cout, tiles, bpc,
+                bestS, bestChunk, tiles * bestS, best * 1e6);
+    return (int)bestS;
+}
+static long wgrad_ws_floats(long S, long KN) { return (S + (S > 64 ? (S + 31) / 32 : 0)) * KN; }
+
 long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     const long M = (long)B * Ho * Wo, K = (long)KH * KW * Cin;
     const long S = wgrad_splits(M, K, Cout);
-    return (S + (S > 64 ? (S + 31) / 32 : 0)) * K * Cout;   // slabs (+ first-level partial sums); one slab even for S = 1
-                                                            // (accumulating launches stage their single slab)
+    long need = wgrad_ws_floats(S, K * Cout);   // slabs (+ first-level partial sums); one slab even for S = 1
+                                                // (accumulating launches stage their single slab)
+    if (wgrad_tr_enabled() && Wo % 4 == 0) {    // the transposed-staging kernel may take this geometry: its own split
+        const long need_tr = wgrad_ws_floats(wgrad_tr_splits(M, K, Cout, nullptr), K * Cout);
+        if (need_tr > need) need = need_tr;
+    }
+    return need;
 }
 
 int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
@@ -1412,10 +1718,22 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     const long need = mmseg_conv2d_wgrad_workspace(B, Ho, Wo, C1 + C2, Cout, KH, KW);
     if (need > ws_floats) return (int)hipErrorInvalidValue;
     const long KN = (long)p.K * Cout;
-    const int S = wgrad_splits(p.M, p.K, Cout);
+    const bool vec = (C1 % 4 == 0) && (C2 % 4 == 0) && aligned16(x1) && (C2 == 0 || aligned16(x2));
+    const long lim = (1L << 31) - 64;
+    const bool fast = vec && (Cout % 4 == 0) && aligned16(dy) && (long)B * p.H1 * p.W1 * C1 * 4 < lim &&
+                      (long)B * H * W * C2 * 4 < lim && (long)p.M * Cout * 4 < lim;
+    // transposed-staging kernel: 4 consecutive pixels of a thread's block lie in one output row
+    const bool tr = fast && wgrad_tr_enabled() && stride == 1 && Wo % 4 == 0 && Ho > 32 / Wo && !(C1 == 8 && C2 == 0 && Cout == 8);
+    int chunk;
+    int S;
+    if (tr) S = wgrad_tr_splits(p.M, p.K, Cout, &chunk);
+    else {
+        S = wgrad_splits(p.M, p.K, Cout);
+        chunk = (p.M + S - 1) / S;
+        chunk = (chunk + 31) / 32 * 32;
+    }
+    if (wgrad_ws_floats(S, KN) > ws_floats) return (int)hipErrorInvalidValue;
     float* tmp = (S > 64) ? ws + (size_t)S * KN : nullptr;
-    int chunk = (p.M + S - 1) / S;
-    chunk = (chunk + 31) / 32 * 32;
     const bool direct = S == 1 && !accumulate;      // a single slab that overwrites dW needs no staging
     q.dy = dy; q.chunk = chunk; q.ws = direct ? dw : ws;
     hipStream_t st = (hipStream_t)stream;
@@ -1427,12 +1745,13 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
         launch_slab_reduce(ws, tmp, dw, KN, nblk, accumulate, st);
         return MMSEG_CHECK_LAUNCH();
     }
-    const bool vec = (C1 % 4 == 0) && (C2 % 4 == 0) && aligned16(x1) && (C2 == 0 || aligned16(x2));
     int rc;
-    const long lim = (1L << 31) - 64;
-    const bool fast = vec && (Cout % 4 == 0) && aligned16(dy) && (long)B * p.H1 * p.W1 * C1 * 4 < lim &&
-                      (long)B * H * W * C2 * 4 < lim && (long)p.M * Cout * 4 < lim;
-    if (fast && Cout > 64) rc = launch_wgrad_fast<128, 128, 2, 2>(q, S, st);
+    if (tr && Cout > 64 && wgrad_tr_bkt(p.K, Cout) == 192) rc = launch_wgrad_tr<192, 128, 2, 2>(q, S, st);
+    else if (tr && Cout > 32 && wgrad_tr_bkt(p.K, Cout) == 192) rc = launch_wgrad_tr<192, 64, 2, 2>(q, S, st);
+    else if (tr && Cout > 64) rc = launch_wgrad_tr<128, 128, 2, 2>(q, S, st);
+    else if (tr && Cout > 32) rc = launch_wgrad_tr<128, 64, 2, 2>(q, S, st);
+    else if (tr) rc = launch_wgrad_tr<128, 32, 4, 1>(q, S, st);
+    else if (fast && Cout > 64) rc = launch_wgrad_fast<128, 128, 2, 2>(q, S, st);
     else if (fast && Cout > 32) rc = launch_wgrad_fast<128, 64, 2, 2>(q, S, st);
     else if (fast) rc = launch_wgrad_fast<128, 32, 4, 1>(q, S, st);
     else if (Cout > 32) rc = launch_wgrad<128, 64, 2, 2>(q, S, vec, st);
