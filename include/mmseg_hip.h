@@ -76,6 +76,12 @@ int mmseg_conv2d_dgrad_s2k4_smallc(const float* dy, const float* w, float* dx, i
  * mmseg_conv2d_wprep_parity back to back in (ph, pw) raster order */
 int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* dx, int B, int Ho, int Wo, int Cout, int H, int W,
                                   int Cin, int KH, int KW, int stride, void* stream);
+/* Data gradient of a stride-1 convolution with few input channels (segmentor c0 8 -> 64, the SPADE shared convolutions 8 -> 128:
+ * model_components/segmentor.py:16, layers/spade.py:29), second half: dx = sum over the taps of the shifted planes of
+ * T [B,Ho,Wo,KH*KW*Cin], which the caller computes with ONE 1x1 mmseg_conv2d_fwd over dy (wt = the Keras kernel itself read as
+ * [KH*KW*Cin][Cout]). */
+int mmseg_conv2d_dgrad_tapsum(const float* T, float* dx, int B, int H, int W, int Ho, int Wo, int Cin, int KH, int KW, int ph, int pw,
+                              void* stream);
 long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 /* dW[KH,KW,Cin,Cout] (+)= sum over output pixels of im2col(x)^T * dy (accumulate != 0 adds to dW: gradient arenas);
  * ws: mmseg_conv2d_wgrad_workspace floats */

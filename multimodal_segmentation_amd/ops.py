@@ -211,6 +211,16 @@ class _Conv2d(torch.autograd.Function):
                     Cin in (1, 4) and N.call('mmseg_conv2d_fast_path', 64, 0, 64, 0):
                 # first layer of a discriminator: N = Cin GEMM -> direct kernel
                 N.call('mmseg_conv2d_dgrad_s2k4_smallc', g, w, d1, B, H, W, Cin, Ho, Wo, Cout)
+            elif stride == 1 and C2 == 0 and not ups and Cin % 4 == 0 and Cin <= 16 and KH * KW > 1 and KH * KW * Cin <= 256 and \
+                    not (Cin == 8 and Cout == 8) and N.call('mmseg_conv2d_fast_path', Cout, 0, KH * KW * Cin, 0):
+                # few input channels: ONE 1x1 GEMM of the gradient against all taps (N = taps * Cin instead of a 32-wide tile
+                # that is mostly padding, dy read once instead of once per tap), then the shifted planes are summed
+                nt = KH * KW * Cin
+                T = _ws('dgrad_taps', B * Ho * Wo * nt, dy.device)[:B * Ho * Wo * nt]
+                # the Keras kernel [KH, KW, Cin, Cout] read as [taps * Cin][Cout] IS the fast layout of that 1x1 convolution
+                N.call('mmseg_conv2d_fwd', g, None, None, w.reshape(-1), None, T, None, B, Ho, Wo, Cout, 0, Ho, Wo, nt, 1, 1, 1, 0, 0,
+                       0, 0, 0, 0.0, 0)
+                N.call('mmseg_conv2d_dgrad_tapsum', T, d1, B, H, W, Ho, Wo, Cin, KH, KW, ph, pw)
             elif tr and stride == 2 and C2 == 0 and not ups and N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0) and \
                     min(taps[0] + taps[1]) > 0:
                 # strided convolution: the parity classes of the input pixels, each an exact stride-1 convolution, batched

@@ -73,6 +73,8 @@ def conv2d_wprep(w, out, KH, KW, Cin, Cout, mode):
 def conv2d_fwd(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, transposed, act,
                alpha, nsplit1):
     xin = _logical_input(x1, x2, B, H, W, C1, C2, ups).permute(0, 3, 1, 2)
+    if w is None:      # only the fast layout was supplied: [Cout][KH*KW][Cin]
+        w = wt.reshape(Cout, KH * KW, C1 + C2).permute(1, 2, 0)
     wk = w.reshape(KH, KW, C1 + C2, Cout).permute(3, 2, 0, 1)
     if transposed:
         # zero-dilate the input by `stride`, then a stride-1 correlation with padding (ph, pw), cropped to Ho x Wo
@@ -108,6 +110,19 @@ def bn_infer_fold(gamma, beta, mm, mv, conv_bias, scale, shift, C, eps):
     scale.copy_(sc)
     shift.copy_(beta - mm * sc + (conv_bias * sc if conv_bias is not None else 0.0))
     return 0
+
+
+def conv2d_dgrad_tapsum(T, dx, B, H, W, Ho, Wo, Cin, KH, KW, ph, pw):
+    t = T.reshape(B, Ho, Wo, KH * KW, Cin)
+    out = torch.zeros(B, H, W, Cin, dtype=T.dtype)
+    for kh in range(KH):
+        for kw in range(KW):
+            # dx[h, w] += T[h + ph - kh, w + pw - kw, tap]
+            h0, h1 = max(0, kh - ph), min(H, Ho + kh - ph)
+            w0, w1 = max(0, kw - pw), min(W, Wo + kw - pw)
+            if h1 > h0 and w1 > w0:
+                out[:, h0:h1, w0:w1] += t[:, h0 + ph - kh:h1 + ph - kh, w0 + pw - kw:w1 + pw - kw, kh * KW + kw]
+    dx.copy_(out.reshape(dx.shape)); return 0
 
 
 def conv2d_wgrad_workspace(B, Ho, Wo, Cin, Cout, KH, KW):

@@ -112,6 +112,9 @@ CONV_CASES = [
     (2, 18, 22, 8, 0, 64, 3, 1, 'same', 'relu', False),        # segmentor c0: its data gradient is a 64 -> 8 3x3 launch (N = 8)
     (3, 17, 19, 64, 0, 8, 3, 1, 'same', 'leaky', False),       # N = 8 on the 32-wide fast tile, odd sizes
     (3, 17, 19, 8, 0, 5, 1, 1, 'same', None, False),           # tiny 1x1 head through the generic kernel
+    (2, 20, 21, 8, 0, 64, 3, 1, 'valid', 'leaky', False),      # few input channels, 'valid': data gradient = 1x1 GEMM over the taps + tap sum
+    (2, 16, 20, 4, 0, 32, 3, 1, 'same', None, False),          # Cin = 4 through the same path
+    (1, 24, 24, 16, 0, 128, 3, 1, 'same', 'relu', False),      # Cin = 16: 144 GEMM columns
 ]
 
 
