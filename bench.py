@@ -6,14 +6,18 @@ A "step" = DAFNetExecutor.train_batch = supervised_trainer.fit + 2 x D_Mask_trai
 incl. the fake-pool generation, Adam updates and BatchNorm moving-average updates -- nothing is skipped.  Inputs
 (synthetic, seeded) are resident in HBM before the timed region.  Metric: paired 2-D slices per second, whole job.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]         # N > 1: starts its N ranks itself (child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Extra fields of the JSON line:
-  roofline     -- the implicit-GEMM convolution kernel (conv_fwd_kernel, used by forward and data-gradient launches):
-                  algorithmic FLOPs (2*M*K*N per launch, from the launch geometry) / time, both accumulated with HIP
-                  events around every such launch inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s)
-  cpu_baseline -- the oracle (torch-CPU restatement, "port") timed on this box's host cores on a bounded sample
+  roofline         -- the DOMINANT kernel instance of the step (largest GPU time), under the name rocprofv3 reports for it, e.g.
+                      conv_fast_kernel<128, 128, 2, 2, 0>: algorithmic FLOPs (2*M*K*N per launch, from the launch geometry) / HIP-event
+                      time of the sampled launches inside the timed region, against the MFMA peak of the compute dtype;
+                      `traffic` = HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same workload
+                      (profiles/r02_conv_traffic.json, keyed by workload and kernel name; null when the workload was not profiled)
+  roofline_kernels -- the same entry for every convolution kernel instance with >= 0.5 ms of GPU time per step
+  roofline_family  -- the two families of round 1 (all forward + data-gradient launches / all weight-gradient launches)
+  cpu_baseline     -- the oracle (torch-CPU restatement, "port") timed on this box's host cores on a bounded sample
 """
 import argparse
 import json
@@ -34,6 +38,31 @@ DTYPE_NAME = {'f32': 'fp32', 'bf16': 'bf16 MFMA operands (fp32 accumulate)', 'f1
 TFLOP_PER_PAIR = {('film', 256): 1.630, ('spade', 256): 2.871, ('mmsdnet', 256): 1.469, ('mmsdnet', 320): 2.296}   # BASELINE.md section 4 (conv MACs x 2)
 
 
+_FAMILY = {1: 'conv_fast_kernel', 2: 'conv_fwd_kernel', 3: 'conv_direct_kernel', 4: 'conv_fast_batched_kernel',
+           5: 'conv_dgrad_s2k4_smallc_kernel', 6: 'conv_wgrad_tr_kernel', 7: 'conv_wgrad_fast_kernel', 8: 'conv_wgrad_kernel',
+           9: 'conv_wgrad_c8_kernel'}
+
+
+def kernel_name(kid, prec):
+    """mmseg_conv2d_last_kernel() id -> the kernel name rocprofv3 reports (template arguments included)"""
+    fam, rest = kid // 1000000, kid % 1000000
+    flag, rest = rest // 500000, rest % 500000
+    bm, bn = rest // 1000, rest % 1000
+    wm, wn = (4, 1) if bn == 32 else (2, 2)
+    tf = 'true' if flag else 'false'
+    if fam in (1, 4, 7):
+        return '%s<%d, %d, %d, %d, %d>' % (_FAMILY[fam], bm, bn, wm, wn, prec)
+    if fam in (2, 8):
+        return '%s<%d, %d, %d, %d, %s>' % (_FAMILY[fam], bm, bn, wm, wn, tf)
+    if fam == 6:
+        return '%s<%d, %d, %d, %d, %d, %s>' % (_FAMILY[fam], bm, bn, wm, wn, prec, tf)
+    if fam == 3:
+        return 'conv_direct_kernel<8, 8, 3>'
+    if fam == 5:
+        return 'conv_dgrad_s2k4_smallc_kernel<%d>' % bm
+    return _FAMILY.get(fam, 'kernel_%d' % kid)
+
+
 class ConvTimer(object):
     """HIP-event timing of every convolution launch on the compute stream (torch's current stream IS the stream
     the kernels are launched on).  Events are only read after the timed region."""
@@ -47,6 +76,8 @@ class ConvTimer(object):
         self.stride = max(1, int(stride))
         self.seen = 0
         self.counts = {}      # kind -> total launches in the timed region (sampled or not)
+        self.kcounts = {}     # rocprof kernel name -> total launches in the timed region
+        self.prec = 0
 
     def install(self):
         from multimodal_segmentation_amd import _native
@@ -98,13 +129,16 @@ class ConvTimer(object):
                     shape = ('wgrad', B, H, W, C1, C2, Cout, KH, KW, 'ups' if ups else '')
                 timer.counts[kind] = timer.counts.get(kind, 0) + 1
                 timer.seen += 1
-                if timer.seen % timer.stride:
-                    return timer._orig(name, *args)
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
+                sampled = timer.seen % timer.stride == 0
+                if sampled:
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
                 rc = timer._orig(name, *args)
-                e.record()
-                timer.records.append((kind, flops, nbytes, s, e, shape))
+                kname = kernel_name(timer._orig('mmseg_conv2d_last_kernel'), timer.prec)     # which template instance ran
+                timer.kcounts[kname] = timer.kcounts.get(kname, 0) + 1
+                if sampled:
+                    e.record()
+                    timer.records.append((kind, flops, nbytes, s, e, shape, kname))
                 return rc
             return timer._orig(name, *args)
         _native.call = call
@@ -112,7 +146,7 @@ class ConvTimer(object):
     def breakdown(self, steps):
         """per-shape table (stderr): launches/step, ms/step, TFLOP/s -- where the convolution time of a step goes"""
         agg = {}
-        for kind, flops, nbytes, s, e, shape in self.records:
+        for kind, flops, nbytes, s, e, shape, _k in self.records:
             d = agg.setdefault(shape, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e)
@@ -125,12 +159,14 @@ class ConvTimer(object):
 
     def summary(self):
         out = {}
-        for kind, flops, nbytes, s, e, _ in self.records:
-            d = out.setdefault(kind, {'flops': 0.0, 'ms': 0.0, 'launches': 0, 'bytes': 0.0})
-            d['flops'] += flops
-            d['bytes'] += nbytes
-            d['ms'] += s.elapsed_time(e)
-            d['launches'] += 1
+        for kind, flops, nbytes, s, e, _, kname in self.records:
+            ms = s.elapsed_time(e)
+            for key in (kind, ('kernel', kname)):
+                d = out.setdefault(key, {'flops': 0.0, 'ms': 0.0, 'launches': 0, 'bytes': 0.0})
+                d['flops'] += flops
+                d['bytes'] += nbytes
+                d['ms'] += ms
+                d['launches'] += 1
         return out
 
 
@@ -301,6 +337,7 @@ def main():
     ex.init_train_data(device_resident=True, slices_per_volume=spv)
 
     timer = ConvTimer(1 if args.conv_breakdown else args.conv_timer_stride)
+    timer.prec = {'f32': 0, 'bf16': 1, 'f16': 2}[args.dtype]
     if not args.no_conv_timer:
         timer.install()
 
@@ -358,34 +395,45 @@ def main():
         line['conv_roofline_frac_whole_step'] = TFLOP_PER_PAIR[key] * value / world / FP32_MFMA_PEAK_TFLOPS
     if rank == 0:
         summ = timer.summary() if not args.no_conv_timer else {}
+        # HBM bytes per launch from rocprofv3 PMC passes of THIS workload (tools/pmc_traffic.py), keyed by workload and kernel
+        wkey = '%s-%s-%d-bs%d-%s-lmix%g' % (args.model if args.model != 'mmsdnet' or args.modalities == 2 else 'mmsdnet3',
+                                          args.decoder, H, args.batch, args.dtype, args.l_mix)
         traffic = {}
-        tpath = os.path.join(ROOT, 'profiles', 'r01_conv_traffic.json')
-        if os.path.exists(tpath) and (args.decoder, H, args.batch, args.l_mix) == ('film', 256, 8, 1.0):
-            traffic = json.load(open(tpath))     # HBM bytes per launch from rocprofv3 PMC passes of this same workload
-        k = summ.get('conv_fwd_kernel')
+        tpath = os.path.join(ROOT, 'profiles', 'r02_conv_traffic.json')
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get('workloads', {}).get(wkey, {})
         peak = BF16_MFMA_PEAK_TFLOPS if args.dtype in ('bf16', 'f16') else FP32_MFMA_PEAK_TFLOPS
-        if k:
+        prec_note = '%s MFMA operands (fp32 tensors in HBM, fp32 accumulation)' % args.dtype if args.dtype != 'f32' else 'fp32 MFMA'
+
+        def entry(k, launches, label):
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
-            line['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (implicit-GEMM %s MFMA; forward + data-gradient launches)'
-                                                           % ('%s (fp32 tensors in HBM, fp32 accumulation)' % args.dtype if args.dtype != 'f32' else 'fp32'),
-                                'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                                'traffic': traffic.get('conv_fwd', {}).get('hbm_bytes_per_launch'),
-                                'algorithmic_bytes_per_launch': k['bytes'] / k['launches'],
-                                'flops_per_launch': k['flops'] / k['launches'],
-                                'launches': timer.counts.get('conv_fwd_kernel', k['launches']), 'timed_launches': k['launches'],
-                                'sampling': 'every %d-th convolution launch of the timed region bracketed by HIP events' % timer.stride,
-                                'avg_launch_ms': k['ms'] / k['launches'],
-                                'gpu_ms_per_step': k['ms'] / k['launches'] * timer.counts.get('conv_fwd_kernel', k['launches']) / args.steps}
-        w = summ.get('conv_wgrad_kernel')
-        if w:
-            ach = w['flops'] / (w['ms'] * 1e-3) / 1e12
-            line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv_wgrad_kernel (+ slab reduce)', 'achieved': ach,
-                                      'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                                      'traffic': traffic.get('conv_wgrad', {}).get('hbm_bytes_per_launch'),
-                                      'algorithmic_bytes_per_launch': w['bytes'] / w['launches'],
-                                      'launches': timer.counts.get('conv_wgrad_kernel', w['launches']), 'timed_launches': w['launches'],
-                                      'avg_launch_ms': w['ms'] / w['launches'],
-                                      'gpu_ms_per_step': w['ms'] / w['launches'] * timer.counts.get('conv_wgrad_kernel', w['launches']) / args.steps}
+            avg = k['ms'] / k['launches']
+            return {'bound': 'mfma', 'kernel': label, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                    'traffic': None, 'algorithmic_bytes_per_launch': k['bytes'] / k['launches'],
+                    'flops_per_launch': k['flops'] / k['launches'], 'launches': launches, 'timed_launches': k['launches'],
+                    'avg_launch_ms': avg, 'gpu_ms_per_step': avg * launches / args.steps}
+        per_kernel = []
+        for key, k in summ.items():
+            if isinstance(key, tuple) and k['ms'] > 0:
+                ent = entry(k, timer.kcounts.get(key[1], k['launches']), key[1])
+                ent['traffic'] = traffic.get('kernels', {}).get(key[1], {}).get('hbm_bytes_per_launch')
+                per_kernel.append(ent)
+        per_kernel.sort(key=lambda e: -e['gpu_ms_per_step'])
+        if per_kernel:
+            # the dominant kernel instance of the step (largest GPU time), named as rocprofv3 names it
+            line['roofline'] = dict(per_kernel[0], precision=prec_note,
+                                    sampling='every %d-th convolution launch of the timed region bracketed by HIP events' % timer.stride,
+                                    traffic_source=('profiles/r02_conv_traffic.json[%s]' % wkey) if per_kernel[0]['traffic'] else None)
+            line['roofline_kernels'] = [e for e in per_kernel if e['gpu_ms_per_step'] >= 0.5]
+        fam = {}
+        for kind, label in (('conv_fwd_kernel', 'forward + data-gradient convolution launches (all template instances)'),
+                            ('conv_wgrad_kernel', 'weight-gradient launches incl. the slab reduction (all template instances)')):
+            k = summ.get(kind)
+            if k:
+                fam[kind] = entry(k, timer.counts.get(kind, k['launches']), label)
+                fam[kind]['traffic'] = traffic.get('families', {}).get('conv_fwd' if kind == 'conv_fwd_kernel' else 'conv_wgrad', {}).get('hbm_bytes_per_launch')
+        if fam:
+            line['roofline_family'] = fam
         if world == 1 and not args.no_cpu_baseline and args.model == 'dafnet':
             _progress('cpu baseline (oracle, bounded sample)')
             line['cpu_baseline'] = cpu_baseline(H, args.decoder, args.batch)

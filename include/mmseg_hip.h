@@ -56,6 +56,11 @@ int mmseg_get_conv_precision(void);
 int mmseg_conv2d_fwd_scaled(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, const float* oscale,
                             float* y, int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                             int pad_h, int pad_w, int ups, int act, float alpha, void* stream);
+/* which kernel template the last convolution entry point launched: family * 1000000 + 500000 * flag + (M | K tile) * 1000 + N tile (flag:
+ * 16-byte gather of the generic kernels / two inputs of conv_wgrad_tr_kernel); families
+ * 1 conv_fast_kernel, 2 conv_fwd_kernel, 3 conv_direct_kernel, 4 conv_fast_batched_kernel, 5 conv_dgrad_s2k4_smallc_kernel,
+ * 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel (profiling aid, no launch) */
+int mmseg_conv2d_last_kernel(void);
 /* fast path (Cin % 32 == 0, not transposed): K tiles lie inside one tap, gather by buffer loads, weights read from
  * `wt` = the kernel re-laid out as [Cout][K] by mmseg_conv2d_wprep (mode 0 forward, mode 1 data gradient incl. the
  * spatial flip); pass wt = NULL to force the generic kernel. */
