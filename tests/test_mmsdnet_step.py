@@ -63,27 +63,13 @@ def test_mmsdnet_iteration(nmod, device):
     ho = orc.generator_step_n([t[k] for k in xk], [t[k] for k in mk], teps, True)
     oo = orc.last_outputs
     teacher = [oo['s%d' % (i + 1)].detach().float().to(device) for i in range(nmod)]
-    graph = model.supervised_trainer.graph_fn
-
-    def graph_tf(ins, training=True, eps=None):      # teacher forcing: replace the encoders' rounded outputs
-        enc = model.Encoders_Anatomy
-        orig = [e.forward for e in enc]
-        from multimodal_segmentation_amd import ops
-        for i in range(nmod):
-            enc[i].forward = (lambda x, training=False, _f=orig[i], _t=teacher[i]: ops.ste_replace(_f(x, training=training), _t))
-        try:
-            return graph(ins, training=training, eps=eps)
-        finally:
-            for i in range(nmod):
-                enc[i].forward = orig[i]
-    model.supervised_trainer.graph_fn = graph_tf
     seg_t = [d[mk[j]] for j in model.seg_target_modalities(True)]          # 5 channels; Dice reads the first 4
     rec_t = [d[xk[j]] for j in model.rec_target_modalities()]
     if nmod == 2:       # the reference's target lists (mmsdnet_executor.py:254-258)
         assert [id(a) for a in seg_t] == [id(d[k]) for k in ('m1', 'm2', 'm2', 'm2', 'm1', 'm1')]
         assert [id(a) for a in rec_t] == [id(d[k]) for k in ('x1', 'x2', 'x2', 'x2', 'x1', 'x1')]
-    h = model.supervised_trainer.fit([d[k] for k in xk], seg_t + [1.0] * n + rec_t + [0.0] * n, eps=eps)
-    model.supervised_trainer.graph_fn = graph
+    # teacher-forced at the Rounding boundary through the same `teacher_s` hook of the graph as the DAFNet tests
+    h = model.supervised_trainer.fit([d[k] for k in xk], seg_t + [1.0] * n + rec_t + [0.0] * n, eps=eps, teacher_s=teacher)
     outs = model.supervised_trainer.last_outputs
     ref = oo['m_list'] + oo['adv_list'] + oo['rec_list'] + oo['kl_list']
     assert len(outs) == len(ref) == 4 * n
