@@ -150,6 +150,17 @@ int mmseg_bn_infer_fold(const float* gamma, const float* beta, const float* mov_
 int mmseg_bn_apply(const float* x, const float* scale, const float* shift, float* y, long M, int C, int relu, void* stream);
 int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean, const float* invstd,
                  float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, int accumulate, void* stream);
+/* Synchronised BatchNorm over data-parallel ranks (build-defined option conf.sync_bn; the reference is single device, SURVEY 8e iii):
+ * the two halves of mmseg_bn_stats / mmseg_bn_bwd, the caller exchanging [2][C] floats in between (all-gather of (mean, biased
+ * variance) in rank order; all-reduce(sum) of (sum g, sum g*xhat)).  stat2 / sums: [2][C]; gathered: [R][2][C]; coef: [3][C]. */
+int mmseg_bn_stats_local(const float* x, float* stat2, float* ws, long M, int C, void* stream);
+int mmseg_bn_stats_combine(const float* gathered, int R, const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
+                           float* shift, float* mov_mean, float* mov_var, long M_total, int C, float eps, float momentum, void* stream);
+int mmseg_bn_bwd_sums(const float* dy, const float* y, const float* x, const float* mean, const float* invstd, float* sums, float* ws,
+                      long M, int C, int relu, void* stream);
+int mmseg_bn_bwd_finish(const float* sums_local, const float* sums_global, const float* gamma, const float* mean, const float* invstd,
+                        float* dgamma, float* dbeta, float* coef, int C, long M_total, int accumulate, void* stream);
+int mmseg_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* coef, float* dx, long M, int C, int relu, void* stream);
 /* keras_contrib InstanceNormalization(axis=None) fused with SPADE_COND and LeakyReLU (layers/spade.py:7-33,51-54) */
 int mmseg_in_workspace_floats(int B);
 int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float* ws, int B,

@@ -143,6 +143,76 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ part, const floa
     }
 }
 
+// ---- synchronised BatchNorm across data-parallel ranks (optional; parallel/dp.py) -------------------------------------------
+// Local half of the statistics: per-channel mean and BIASED variance of this rank's rows -> stat2 [2][C].
+__global__ void bn_stats_local_final_kernel(const float* __restrict__ part, const float* __restrict__ x, float* __restrict__ stat2,
+                                            int nblk, int C, long M) {
+    __shared__ float sm[512];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s1, s2;
+    reduce_partials_64x4(part, nblk, C, c, lane, s1, s2, sm);
+    if (c >= C || lane != 0) return;
+    const float invM = 1.f / (float)M;
+    const float d = s1 * invM;
+    float var = s2 * invM - d * d;
+    stat2[c] = x[c] + d;
+    stat2[C + c] = var > 0.f ? var : 0.f;
+}
+// Combine the (mean, biased variance) pairs of R equally sized shards (gathered [R][2][C], fixed rank order -> every rank computes
+// bit-identical statistics): mean = avg(mean_r), var = avg(var_r + (mean_r - mean)^2); then exactly bn_stats_final_kernel's outputs
+// with M_total rows (moving variance from the UNBIASED global variance).
+__global__ void bn_stats_combine_kernel(const float* __restrict__ gathered, int R, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,
+                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mov_mean,
+                                        float* __restrict__ mov_var, long M_total, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mu = 0.f;
+    for (int r = 0; r < R; ++r) mu += gathered[((size_t)r * 2) * C + c];
+    mu /= (float)R;
+    float var = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float dm = gathered[((size_t)r * 2) * C + c] - mu;
+        var += gathered[((size_t)r * 2 + 1) * C + c] + dm * dm;
+    }
+    var /= (float)R;
+    const float is = rsqrtf(var + eps);
+    mean[c] = mu; invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc; shift[c] = beta[c] - mu * sc;
+    if (mov_mean) {
+        const float unb = M_total > 1 ? var * ((float)M_total / (float)(M_total - 1)) : var;
+        mov_mean[c] -= (mov_mean[c] - mu) * (1.f - momentum);
+        mov_var[c] -= (mov_var[c] - unb) * (1.f - momentum);
+    }
+}
+// backward sums of this rank -> sums [2][C] = (sum g, sum g * xhat)
+__global__ void bn_bwd_sums_final_kernel(const float* __restrict__ part, float* __restrict__ sums, int nblk, int C) {
+    __shared__ float sm[512];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s1, s2;
+    reduce_partials_64x4(part, nblk, C, c, lane, s1, s2, sm);
+    if (c >= C || lane != 0) return;
+    sums[c] = s1; sums[C + c] = s2;
+}
+// dgamma / dbeta take THIS rank's sums (the data-parallel gradient all-reduce averages them like every other weight gradient);
+// the dx coefficients take the sums over ALL ranks and the global row count
+__global__ void bn_bwd_finish_kernel(const float* __restrict__ local, const float* __restrict__ global, const float* __restrict__ gamma,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, float* __restrict__ coef, int C, long M_total, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dgamma) {
+        if (accumulate) { dbeta[c] += local[c]; dgamma[c] += local[C + c]; }
+        else { dbeta[c] = local[c]; dgamma[c] = local[C + c]; }
+    }
+    const float s1 = global[c], s2 = global[C + c];
+    const float invM = 1.f / (float)M_total, is = invstd[c], ga = gamma[c], mu = mean[c];
+    const float A = ga * is;
+    const float Bc = -ga * is * is * s2 * invM;
+    coef[c] = A; coef[C + c] = Bc; coef[2 * C + c] = -A * s1 * invM - Bc * mu;
+}
+
 // inference: scale/shift from the moving statistics
 __global__ void bn_infer_prep_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mov_mean,
                                      const float* __restrict__ mov_var, float* __restrict__ scale, float* __restrict__ shift,
@@ -372,6 +442,58 @@ int mmseg_bn_stats(const float* x, const float* gamma, const float* beta, float*
                        scale, shift, mov_mean, mov_var, nblk, C, M, eps, momentum);
     return MMSEG_CHECK_LAUNCH();
 }
+// ---- synchronised BatchNorm (data parallel): the two halves of mmseg_bn_stats / mmseg_bn_bwd with the cross-rank exchange
+//      (all-gather of [2][C] statistics, all-reduce of [2][C] sums -- done by the caller) in between -------------------------
+static int bn_launch_partial(int mode, const float* x, const float* dy, const float* y, const float* mean, const float* invstd,
+                             float* ws, long M, int C, int relu, hipStream_t st) {
+    int nblk;
+    if ((C & 63) == 0) {
+        nblk = v4_row_blocks(M, C);
+        const long rpb = (M + nblk - 1) / nblk;
+        if (mode == 0) hipLaunchKernelGGL(bn_partial_v4_kernel<0>, dim3(nblk, C / 64), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
+        else hipLaunchKernelGGL(bn_partial_v4_kernel<1>, dim3(nblk, C / 64), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
+    } else {
+        nblk = norm_blocks(M);
+        const long rpb = (M + nblk - 1) / nblk;
+        if (mode == 0) hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
+        else hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
+    }
+    return nblk;
+}
+int mmseg_bn_stats_local(const float* x, float* stat2, float* ws, long M, int C, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = bn_launch_partial(0, x, nullptr, nullptr, nullptr, nullptr, ws, M, C, 0, st);
+    hipLaunchKernelGGL(bn_stats_local_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, x, stat2, nblk, C, M);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_bn_stats_combine(const float* gathered, int R, const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
+                           float* shift, float* mov_mean, float* mov_var, long M_total, int C, float eps, float momentum, void* stream) {
+    if (R < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_stats_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gathered, R, gamma, beta, mean,
+                       invstd, scale, shift, mov_mean, mov_var, M_total, C, eps, momentum);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_bn_bwd_sums(const float* dy, const float* y, const float* x, const float* mean, const float* invstd, float* sums, float* ws,
+                      long M, int C, int relu, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = bn_launch_partial(1, x, dy, y, mean, invstd, ws, M, C, relu, st);
+    hipLaunchKernelGGL(bn_bwd_sums_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, sums, nblk, C);
+    return MMSEG_CHECK_LAUNCH();
+}
+// dgamma / dbeta (may be NULL) <- local sums; coef [3][C] <- global sums and M_total; then dx = mmseg_bn_bwd_apply
+int mmseg_bn_bwd_finish(const float* sums_local, const float* sums_global, const float* gamma, const float* mean, const float* invstd,
+                        float* dgamma, float* dbeta, float* coef, int C, long M_total, int accumulate, void* stream) {
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums_local, sums_global, gamma, mean,
+                       invstd, dgamma, dbeta, coef, C, M_total, accumulate);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* coef, float* dx, long M, int C, int relu, void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, dy, y, x, coef, dx, n4, C / 4, relu);
+    return MMSEG_CHECK_LAUNCH();
+}
+
 int mmseg_bn_infer_prep(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float* scale, float* shift,
                         int C, float eps, void* stream) {
     hipLaunchKernelGGL(bn_infer_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mov_mean, mov_var, scale, shift, C, eps);

@@ -297,8 +297,17 @@ class _BatchNormTrain(torch.autograd.Function):
         M = x.numel() // C
         stats = _new((4, C), x)  # mean, invstd, scale, shift
         ws = _ws('norm', N.call('mmseg_norm_workspace_floats', C), x.device)
-        N.call('mmseg_bn_stats', x, gamma, beta, stats[0], stats[1], stats[2], stats[3], mov_mean, mov_var, ws, M, C,
-               BN_EPS, BN_MOMENTUM)
+        ctx.sync = dp.sync_bn()
+        if ctx.sync:
+            # statistics over the global batch: (mean, biased variance) of this rank's rows, gathered in rank order, combined
+            local = _new((2, C), x)
+            N.call('mmseg_bn_stats_local', x, local, ws, M, C)
+            gathered = dp.all_gather_rows(local.reshape(-1))
+            N.call('mmseg_bn_stats_combine', gathered, dp.world_size(), gamma, beta, stats[0], stats[1], stats[2], stats[3],
+                   mov_mean, mov_var, M * dp.world_size(), C, BN_EPS, BN_MOMENTUM)
+        else:
+            N.call('mmseg_bn_stats', x, gamma, beta, stats[0], stats[1], stats[2], stats[3], mov_mean, mov_var, ws, M, C,
+                   BN_EPS, BN_MOMENTUM)
         y = _new(x.shape, x)
         N.call('mmseg_bn_apply', x, stats[2], stats[3], y, M, C, int(relu))
         ctx.relu = bool(relu)
@@ -315,6 +324,20 @@ class _BatchNormTrain(torch.autograd.Function):
         dx = _new(x.shape, x)
         coef = _ws('bn_coef', 3 * C, x.device)
         ws = _ws('norm', N.call('mmseg_norm_workspace_floats', C), x.device)
+        if ctx.sync:
+            # sums of this rank -> dgamma / dbeta (averaged over ranks with the other weight gradients); sums over all ranks -> dx
+            local = _new((2, C), x)
+            N.call('mmseg_bn_bwd_sums', dy, y, x, stats[0], stats[1], local, ws, M, C, int(ctx.relu))
+            glob = dp.all_reduce_sum(local.clone())
+            if ctx.ggrad is not None and ctx.bgrad is not None:
+                N.call('mmseg_bn_bwd_finish', local, glob, ctx.gamma, stats[0], stats[1], ctx.ggrad, ctx.bgrad, coef, C,
+                       M * dp.world_size(), 1)
+            else:
+                assert ctx.ggrad is None and ctx.bgrad is None, 'BatchNorm gamma and beta are trained or frozen together'
+                N.call('mmseg_bn_bwd_finish', local, glob, ctx.gamma, stats[0], stats[1], None, None, coef, C, M * dp.world_size(), 0)
+            N.call('mmseg_bn_bwd_apply', dy, y, x, coef, dx, M, C, int(ctx.relu))
+            _grad_done(ctx.ggrad, ctx.bgrad)
+            return (dx,) + (None,) * 8
         if ctx.ggrad is not None and ctx.bgrad is not None:
             # the final reduction adds dgamma / dbeta straight into the gradient-arena views
             N.call('mmseg_bn_bwd', dy, y, x, ctx.gamma, stats[0], stats[1], dx, ctx.ggrad, ctx.bgrad, coef, ws, M, C, int(ctx.relu), 1)

@@ -103,6 +103,29 @@ def average_state(models):
     ops.bump_weight_version()
 
 
+def set_sync_bn(flag):
+    """conf.sync_bn (build-defined, default False): training-mode BatchNorm statistics over the GLOBAL batch of all ranks instead
+    of per-rank "ghost" statistics -- a data-parallel step then equals the single-device step on the concatenated batch"""
+    _state['sync_bn'] = bool(flag)
+
+
+def sync_bn():
+    return enabled() and _state.get('sync_bn', False)
+
+
+def all_gather_rows(local):
+    """[n] tensor of every rank -> [world, n] in rank order (identical on every rank)"""
+    out = torch.empty((dist.get_world_size(),) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous()) if hasattr(dist, 'all_gather_into_tensor') and local.is_cuda else \
+        dist.all_gather(list(out.unbind(0)), local.contiguous())
+    return out
+
+
+def all_reduce_sum(t):
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def class_sum_hook():
     if not enabled():
         return None

@@ -112,6 +112,52 @@ def bn_infer_fold(gamma, beta, mm, mv, conv_bias, scale, shift, C, eps):
     return 0
 
 
+def bn_stats_local(x, stat2, ws, M, C):
+    xr = x.reshape(M, C)
+    stat2.copy_(torch.stack([xr.mean(0), xr.var(0, unbiased=False)]).reshape(stat2.shape)); return 0
+
+
+def bn_stats_combine(gathered, R, gamma, beta, mean, invstd, scale, shift, mov_mean, mov_var, M_total, C, eps, momentum):
+    g = gathered.reshape(R, 2, C)
+    mu = g[:, 0].mean(0)
+    var = (g[:, 1] + (g[:, 0] - mu) ** 2).mean(0)
+    is_ = torch.rsqrt(var + eps)
+    mean.copy_(mu); invstd.copy_(is_); scale.copy_(gamma * is_); shift.copy_(beta - mu * gamma * is_)
+    if mov_mean is not None:
+        unb = var * (M_total / (M_total - 1.0)) if M_total > 1 else var
+        mov_mean.sub_((mov_mean - mu) * (1.0 - momentum)); mov_var.sub_((mov_var - unb) * (1.0 - momentum))
+    return 0
+
+
+def bn_bwd_sums(dy, y, x, mean, invstd, sums, ws, M, C, relu):
+    g = dy.reshape(M, C)
+    if relu:
+        g = g * (y.reshape(M, C) > 0)
+    xh = (x.reshape(M, C) - mean) * invstd
+    sums.copy_(torch.stack([g.sum(0), (g * xh).sum(0)]).reshape(sums.shape)); return 0
+
+
+def bn_bwd_finish(local, glob, gamma, mean, invstd, dgamma, dbeta, coef, C, M_total, accumulate):
+    l, g = local.reshape(2, C), glob.reshape(2, C)
+    if dgamma is not None:
+        if accumulate:
+            dbeta.add_(l[0]); dgamma.add_(l[1])
+        else:
+            dbeta.copy_(l[0]); dgamma.copy_(l[1])
+    A = gamma * invstd
+    Bc = -gamma * invstd * invstd * g[1] / M_total
+    Cc = -A * g[0] / M_total - Bc * mean
+    coef[:3 * C].copy_(torch.cat([A, Bc, Cc])); return 0
+
+
+def bn_bwd_apply(dy, y, x, coef, dx, M, C, relu):
+    g = dy.reshape(M, C)
+    if relu:
+        g = g * (y.reshape(M, C) > 0)
+    A, Bc, Cc = coef[:C], coef[C:2 * C], coef[2 * C:3 * C]
+    dx.copy_((A * g + Bc * x.reshape(M, C) + Cc).reshape(dx.shape)); return 0
+
+
 def conv2d_dgrad_tapsum(T, dx, B, H, W, Ho, Wo, Cin, KH, KW, ph, pw):
     t = T.reshape(B, Ho, Wo, KH * KW, Cin)
     out = torch.zeros(B, H, W, Cin, dtype=T.dtype)

@@ -58,6 +58,19 @@ def _tiny_seg_trainer():
     return m, tr
 
 
+def _segmentor_trainer(model):
+    """the product's Segmentor (conv - BatchNorm - ReLU twice + softmax head) as a trainer of its own under Dice + 0.01 * BCE"""
+    from multimodal_segmentation_amd import nn
+    from multimodal_segmentation_amd.models.trainer import Trainer, OutputSpec
+    seg = model.Segmentor
+    return Trainer('seg_only', lambda ins, training=True: [seg(ins[0], training=training)], [OutputSpec('Segmentor', 'dice_bce', 10.0)],
+                   [seg], nn.Adam(1e-4), num_masks=4)
+
+
+def _seg_input(B):
+    return (np.random.RandomState(12).rand(B, H, H, 8) > 0.7).astype(np.float32)
+
+
 def _tiny_input(B):
     return np.random.RandomState(11).standard_normal((B, H, H, 8)).astype(np.float32)
 
@@ -87,6 +100,13 @@ def _worker_body(rank, world, port, q):
     h = model.D_Mask_trainer.fit([d['dm_m1'][sl], d['dm_m2'][sl]], [1.0, 0.0])
     dm_after = model.D_Mask.arena.clone()
     assert dp._state['last_overlapped'] == 0 and dp._state['last_collectives'] == 1     # regularised arena: reduced at the end
+    # ---- synchronised BatchNorm: the BatchNorm-ed Segmentor on 2 ranks x batch 1 == the single-process step on the batch of 2 ----
+    dp.set_sync_bn(True)
+    assert dp.sync_bn()
+    _segmentor_trainer(model).fit([_seg_input(2)[sl]], [d['m1'][sl]])
+    seg_grad = model.Segmentor.grad_arena.clone().numpy()
+    seg_state = model.Segmentor.state_arena.clone().numpy()
+    dp.set_sync_bn(False)
     # ---- generator step: replicas stay in sync, class sums are global -----------------------------------------
     ones = np.ones((1, 1), np.float32)
     model.supervised_trainer.fit([d['x1'][sl], d['x2'][sl], d['z1'][sl], d['z2'][sl]],
@@ -105,7 +125,7 @@ def _worker_body(rank, world, port, q):
     sig = torch.cat([m.arena.double().sum().reshape(1) for m in gens])
     gathered = [torch.zeros_like(sig) for _ in range(world)]
     dist.all_gather(gathered, sig)
-    q.put((rank, dm_after.numpy(), [g.numpy() for g in gathered], float(h.history['loss'][0]), tiny_grad))
+    q.put((rank, dm_after.numpy(), [g.numpy() for g in gathered], float(h.history['loss'][0]), tiny_grad, seg_grad, seg_state))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -147,6 +167,13 @@ def _single_process_reference(res):
     tiny, ttr = _tiny_seg_trainer()
     ttr.fit([_tiny_input(2)], [d['m1']])
     gref = tiny.grad_arena.numpy()
+    # synchronised BatchNorm: gradients AND moving statistics of the DP step equal the global-batch step's
+    assert np.array_equal(res[0][5], res[1][5]) and np.array_equal(res[0][6], res[1][6]), 'SyncBN replicas diverged'
+    _segmentor_trainer(model).fit([_seg_input(2)], [d['m1']])
+    sg, ss = model.Segmentor.grad_arena.numpy(), model.Segmentor.state_arena.numpy()
+    assert np.abs(res[0][5] - sg).max() < 2e-5 * max(1.0, np.abs(sg).max()), \
+        'SyncBN gradient differs from the global-batch gradient: %g vs scale %g' % (np.abs(res[0][5] - sg).max(), np.abs(sg).max())
+    assert np.abs(res[0][6] - ss).max() < 1e-5, 'SyncBN moving statistics differ: %g' % np.abs(res[0][6] - ss).max()
     assert np.abs(res[0][4] - gref).max() < 1e-5 * max(1.0, np.abs(gref).max()), \
         'DP segmentation-loss gradient differs from the global-batch gradient: %g vs scale %g' % (
             np.abs(res[0][4] - gref).max(), np.abs(gref).max())

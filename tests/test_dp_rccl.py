@@ -78,3 +78,48 @@ def test_rccl_single_rank_step_is_bitwise_the_plain_step():
     assert np.array_equal(got['dm'], ref['dm']), 'D_Mask weights differ after two RCCL-reduced steps'
     for a, b in zip(got['gen'], ref['gen']):
         assert np.array_equal(a, b), 'generator weights differ after two RCCL-reduced steps'
+
+
+@pytest.mark.gpu
+def test_sync_batchnorm_kernels_single_rank_equal_plain_batchnorm():
+    """conf.sync_bn over RCCL with one rank: the split kernels (local statistics -> all-gather -> combine; local sums -> all-reduce
+    -> finish -> apply) must reproduce the fused BatchNorm kernels on the same batch (the exact multi-rank equivalence with the
+    global-batch step is tests/test_dp_gloo.py's, on the CPU stand-in)."""
+    import torch.distributed as dist
+    from multimodal_segmentation_amd import nn
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from multimodal_segmentation_amd.models.trainer import Trainer, OutputSpec
+    from multimodal_segmentation_amd.parallel import dp
+    torch.cuda.set_device(0)
+    nn.set_default_device('cuda:0')
+    conf = Hh.make_conf(dafnet_config_chaos, H)
+    model = DAFNet(conf)
+    model.build()
+    seg = model.Segmentor
+    w0 = seg.get_weights()
+    s_in = (np.random.RandomState(12).rand(4, H, H, 8) > 0.7).astype(np.float32)
+    d = Hh.make_step_data(4, H, H, seed=6)
+
+    def step():
+        seg.set_weights(w0)
+        tr = Trainer('seg_only', lambda ins, training=True: [seg(ins[0], training=training)], [OutputSpec('Segmentor', 'dice_bce', 10.0)],
+                     [seg], nn.Adam(1e-4), num_masks=4)
+        h = tr.fit([s_in], [d['m1']])
+        torch.cuda.synchronize()
+        return h.history['loss'][0], seg.grad_arena.detach().cpu().numpy().copy(), seg.state_arena.detach().cpu().numpy().copy()
+    ref = step()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        dp.enable(True, force=True)
+        dp.set_sync_bn(True)
+        assert dp.sync_bn()
+        got = step()
+    finally:
+        dp.set_sync_bn(False)
+        dp.enable(False)
+        dist.destroy_process_group()
+    assert abs(got[0] - ref[0]) <= 1e-5 * max(1.0, abs(ref[0]))
+    assert np.abs(got[1] - ref[1]).max() <= 2e-5 * max(1.0, np.abs(ref[1]).max()), np.abs(got[1] - ref[1]).max()
+    assert np.abs(got[2] - ref[2]).max() <= 1e-5, np.abs(got[2] - ref[2]).max()
