@@ -56,6 +56,14 @@ int mmseg_get_conv_precision(void);
 int mmseg_conv2d_fwd_scaled(const float* x1, const float* x2, const float* w, const float* wt, const float* bias, const float* oscale,
                             float* y, int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                             int pad_h, int pad_w, int ups, int act, float alpha, void* stream);
+/* mmseg_conv2d_fwd / _fwd_scaled with 16-bit tensors in HBM (build-defined reduced-precision storage; mmseg_set_conv_precision(1 | 2)
+ * selects bf16 | fp16): io bit 0 = x1, bit 1 = x2 hold 16-bit elements (MFMA fast path only), bit 2 = y / y2 are written 16-bit. */
+int mmseg_conv2d_fwd_t(const void* x1, const void* x2, const float* w, const float* wt, const float* bias, void* y, void* y2,
+                       int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                       int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, int io, void* stream);
+int mmseg_conv2d_fwd_scaled_t(const void* x1, const void* x2, const float* w, const float* wt, const float* bias, const float* oscale,
+                              void* y, int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                              int pad_h, int pad_w, int ups, int act, float alpha, int io, void* stream);
 /* which kernel template the last convolution entry point launched: family * 1000000 + 500000 * flag + (M | K tile) * 1000 + N tile (flag:
  * 16-byte gather of the generic kernels / two inputs of conv_wgrad_tr_kernel); families
  * 1 conv_fast_kernel, 2 conv_fwd_kernel, 3 conv_direct_kernel, 4 conv_fast_batched_kernel, 5 conv_dgrad_s2k4_smallc_kernel,
@@ -88,6 +96,11 @@ int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* d
 int mmseg_conv2d_dgrad_tapsum(const float* T, float* dx, int B, int H, int W, int Ho, int Wo, int Cin, int KH, int KW, int ph, int pw,
                               void* stream);
 long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
+/* mmseg_conv2d_wgrad with 16-bit operands in HBM (reduced-precision modes; stride 1 and Wo % 4 == 0 only): io bit 0 = x1 (and x2),
+ * bit 2 = dy hold 16-bit elements; dw and the workspace stay fp32 */
+int mmseg_conv2d_wgrad_t(const void* x1, const void* x2, const void* dy, float* dw, float* ws, long ws_floats,
+                         int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                         int pad_h, int pad_w, int ups, int accumulate, int io, void* stream);
 /* dW[KH,KW,Cin,Cout] (+)= sum over output pixels of im2col(x)^T * dy (accumulate != 0 adds to dW: gradient arenas);
  * ws: mmseg_conv2d_wgrad_workspace floats */
 int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
@@ -161,6 +174,18 @@ int mmseg_bn_bwd_sums(const float* dy, const float* y, const float* x, const flo
 int mmseg_bn_bwd_finish(const float* sums_local, const float* sums_global, const float* gamma, const float* mean, const float* invstd,
                         float* dgamma, float* dbeta, float* coef, int C, long M_total, int accumulate, void* stream);
 int mmseg_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* coef, float* dx, long M, int C, int relu, void* stream);
+/* ---- reduced-precision STORAGE of the convolutional trunk (csrc/act16.hip; build-defined, BASELINE configs #3 / #5): BatchNorm, 2x2
+ *      max pooling and the gradient of nearest x2 up-sampling on tensors stored as fp32 or a 16-bit type, per tensor: element code
+ *      h = 0 fp32, 1 bf16, 2 fp16.  Arithmetic, statistics and reductions are fp32 as in the fp32 entry points.  C % 64 == 0 for
+ *      the statistics / backward passes.  mmseg_bn_bwd_t: dy, y carry hy; x, dx carry hx; dgamma / dbeta may be NULL. ---- */
+int mmseg_bn_stats_t(const void* x, const float* gamma, const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                     float* mov_mean, float* mov_var, float* ws, long M, int C, float eps, float momentum, int hx, void* stream);
+int mmseg_bn_apply_t(const void* x, const float* scale, const float* shift, void* y, long M, int C, int relu, int hx, int hy, void* stream);
+int mmseg_bn_bwd_t(const void* dy, const void* y, const void* x, const float* gamma, const float* mean, const float* invstd, void* dx,
+                   float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, int accumulate, int hx, int hy, void* stream);
+int mmseg_maxpool2_fwd_t(const void* x, void* y, int B, int H, int W, int C, int h, void* stream);
+int mmseg_maxpool2_bwd_t(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, int h, void* stream);
+int mmseg_upsample2_bwd_t(const void* dy, void* dx, int B, int H, int W, int C, int h, void* stream);
 /* keras_contrib InstanceNormalization(axis=None) fused with SPADE_COND and LeakyReLU (layers/spade.py:7-33,51-54) */
 int mmseg_in_workspace_floats(int B);
 int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float* ws, int B,

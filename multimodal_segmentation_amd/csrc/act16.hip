@@ -1,0 +1,328 @@
+// Reduced-precision STORAGE of the convolutional trunk (build-defined extension for BASELINE configs #3 / #5): BatchNorm, 2x2 max
+// pooling and the gradient of nearest x2 up-sampling with every activation / gradient tensor stored either as fp32 or as a 16-bit type
+// (h code 0 = fp32, 1 = bf16, 2 = fp16), chosen per tensor.  Arithmetic, statistics, gamma / beta, moving averages and the
+// per-channel reductions are fp32 exactly as in norm.hip / pointwise.hip (same two-stage, fixed-order reductions -> run-to-run
+// bitwise reproducible); only the loads and stores differ: 8-byte accesses of four 16-bit elements instead of 16-byte accesses of four
+// floats, i.e. half the HBM bytes of these HBM-bound passes.  The fp32 entry points of norm.hip / pointwise.hip are untouched.
+// Reference ops: keras BatchNormalization / MaxPooling2D / UpSampling2D as used in models/unet.py:37-101,
+// model_components/segmentor.py:16-21.
+#include "common.hpp"
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+// four consecutive elements number 4*i4 .. 4*i4+3 of a tensor stored with element code H
+template <int H> __device__ __forceinline__ f32x4 ld4(const void* p, long i4) {
+    if constexpr (H == 0) return reinterpret_cast<const f32x4*>(p)[i4];
+    else if constexpr (H == 1) {
+        const bf16x4_t v = reinterpret_cast<const bf16x4_t*>(p)[i4];
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else {
+        const f16x4_t v = reinterpret_cast<const f16x4_t*>(p)[i4];
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+template <int H> __device__ __forceinline__ void st4(void* p, long i4, f32x4 v) {
+    if constexpr (H == 0) reinterpret_cast<f32x4*>(p)[i4] = v;
+    else if constexpr (H == 1) reinterpret_cast<bf16x4_t*>(p)[i4] = bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    else reinterpret_cast<f16x4_t*>(p)[i4] = f16x4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+}
+template <int H> __device__ __forceinline__ float ld1(const void* p, long i) {
+    if constexpr (H == 0) return reinterpret_cast<const float*>(p)[i];
+    else if constexpr (H == 1) return (float)reinterpret_cast<const __bf16*>(p)[i];
+    else return (float)reinterpret_cast<const _Float16*>(p)[i];
+}
+
+// ---- BatchNorm ------------------------------------------------------------------------------------------------------------------
+// C % 64 == 0 (every BatchNorm of the trunk).  grid (row blocks, C/64), block = 16 float4 column lanes x 16 row lanes.
+// MODE 0: (x - shift, (x - shift)^2), shift = x[0][c]; MODE 1: (g, g * xhat), g = dy * [y > 0 if relu]
+template <int MODE, int HX, int HY>
+__global__ __launch_bounds__(256) void bn16_partial_kernel(const void* __restrict__ x, const void* __restrict__ dy, const void* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float* __restrict__ part, long M, int C, long rows_per_block, int relu) {
+    __shared__ f32x4 sm[2][16][16];
+    const int tid = threadIdx.x, c4 = tid & 15, rl = tid >> 4;
+    const int C4 = C >> 2;
+    const int col = blockIdx.y * 16 + c4;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+        const f32x4 sh = ld4<HX>(x, col);
+#pragma unroll 4
+        for (long r = r0 + rl; r < r1; r += 16) {
+            const f32x4 d = ld4<HX>(x, r * C4 + col) - sh;
+            s1 += d; s2 += d * d;
+        }
+    } else {
+        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[col], is = reinterpret_cast<const f32x4*>(invstd)[col];
+#pragma unroll 4
+        for (long r = r0 + rl; r < r1; r += 16) {
+            f32x4 g = ld4<HY>(dy, r * C4 + col);
+            if (relu) {
+                const f32x4 o = ld4<HY>(y, r * C4 + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+            }
+            s1 += g; s2 += g * (ld4<HX>(x, r * C4 + col) - mu) * is;
+        }
+    }
+    sm[0][rl][c4] = s1; sm[1][rl][c4] = s2;
+    __syncthreads();
+    if (tid < 32) {
+        const int which = tid >> 4, cc = tid & 15;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[which][k][cc];
+        *reinterpret_cast<f32x4*>(part + ((size_t)blockIdx.x * 2 + which) * C + (size_t)(blockIdx.y * 16 + cc) * 4) = t;
+    }
+}
+
+__device__ __forceinline__ void reduce_partials16(const float* __restrict__ part, int nblk, int C, int c, int lane, float& s1, float& s2,
+                                                  float* sm /* 512 floats */) {
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int b = lane; b < nblk; b += 4) { a1 += part[((size_t)b * 2) * C + c]; a2 += part[((size_t)b * 2 + 1) * C + c]; }
+    }
+    sm[threadIdx.x] = a1; sm[256 + threadIdx.x] = a2;
+    __syncthreads();
+    const int cl = threadIdx.x & 63;
+    s1 = sm[cl] + sm[64 + cl] + sm[128 + cl] + sm[192 + cl];
+    s2 = sm[256 + cl] + sm[320 + cl] + sm[384 + cl] + sm[448 + cl];
+}
+
+template <int HX>
+__global__ void bn16_stats_final_kernel(const float* __restrict__ part, const void* __restrict__ x, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,
+                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mov_mean,
+                                        float* __restrict__ mov_var, int nblk, int C, long M, float eps, float momentum) {
+    __shared__ float sm[512];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s1, s2;
+    reduce_partials16(part, nblk, C, c, lane, s1, s2, sm);
+    if (c >= C || lane != 0) return;
+    const float invM = 1.f / (float)M;
+    const float d = s1 * invM;
+    const float mu = ld1<HX>(x, c) + d;
+    float var = s2 * invM - d * d;
+    var = var > 0.f ? var : 0.f;
+    const float is = rsqrtf(var + eps);
+    mean[c] = mu; invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc; shift[c] = beta[c] - mu * sc;
+    if (mov_mean) {
+        const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+        mov_mean[c] -= (mov_mean[c] - mu) * (1.f - momentum);
+        mov_var[c] -= (mov_var[c] - unb) * (1.f - momentum);
+    }
+}
+
+template <int HX, int HY>
+__global__ void bn16_apply_kernel(const void* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  void* __restrict__ y, long n4, int C4, int relu) {
+    const f32x4* S = reinterpret_cast<const f32x4*>(scale);
+    const f32x4* T = reinterpret_cast<const f32x4*>(shift);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        f32x4 v = ld4<HX>(x, i) * S[c] + T[c];
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        st4<HY>(y, i, v);
+    }
+}
+
+__global__ void bn16_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                      const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                      float* __restrict__ coef /* [3][C] */, int nblk, int C, long M, int accumulate) {
+    __shared__ float sm[512];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s1, s2;
+    reduce_partials16(part, nblk, C, c, lane, s1, s2, sm);
+    if (c >= C || lane != 0) return;
+    if (dgamma) {
+        if (accumulate) { dbeta[c] += s1; dgamma[c] += s2; }
+        else { dbeta[c] = s1; dgamma[c] = s2; }
+    }
+    const float invM = 1.f / (float)M, is = invstd[c], ga = gamma[c], mu = mean[c];
+    const float A = ga * is;
+    const float Bc = -ga * is * is * s2 * invM;
+    coef[c] = A; coef[C + c] = Bc; coef[2 * C + c] = -A * s1 * invM - Bc * mu;
+}
+
+template <int HX, int HY>
+__global__ void bn16_bwd_apply_kernel(const void* __restrict__ dy, const void* __restrict__ y, const void* __restrict__ x,
+                                      const float* __restrict__ coef, void* __restrict__ dx, long n4, int C4, int relu) {
+    const f32x4* A = reinterpret_cast<const f32x4*>(coef);
+    const f32x4* Bc = A + C4;
+    const f32x4* Cc = A + 2 * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        f32x4 g = ld4<HY>(dy, i);
+        if (relu) {
+            const f32x4 o = ld4<HY>(y, i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+        st4<HX>(dx, i, A[c] * g + Bc[c] * ld4<HX>(x, i) + Cc[c]);
+    }
+}
+
+// ---- 2x2 max pooling / gradient of nearest x2 up-sampling -------------------------------------------------------------------------
+template <int H>
+__global__ void maxpool16_fwd_kernel(const void* __restrict__ x, void* __restrict__ y, int B, int Hh, int W, int C4) {
+    const int Ho = Hh / 2, Wo = W / 2;
+    const long n = (long)B * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4; long r = i / C4;
+        const int wo = r % Wo; r /= Wo;
+        const int ho = r % Ho; const int b = r / Ho;
+        const long base = (((long)b * Hh + 2 * ho) * W + 2 * wo) * C4 + c;
+        const f32x4 v00 = ld4<H>(x, base), v01 = ld4<H>(x, base + C4), v10 = ld4<H>(x, base + (long)W * C4),
+                    v11 = ld4<H>(x, base + (long)W * C4 + C4);
+        f32x4 m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+        st4<H>(y, i, m);
+    }
+}
+// gradient goes to the FIRST maximum in row-major window order (as in pointwise.hip)
+template <int H>
+__global__ void maxpool16_bwd_kernel(const void* __restrict__ x, const void* __restrict__ y, const void* __restrict__ dy,
+                                     void* __restrict__ dx, int B, int Hh, int W, int C4) {
+    const int Ho = Hh / 2, Wo = W / 2;
+    const long n = (long)B * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4; long r = i / C4;
+        const int wo = r % Wo; r /= Wo;
+        const int ho = r % Ho; const int b = r / Ho;
+        const long base = (((long)b * Hh + 2 * ho) * W + 2 * wo) * C4 + c;
+        const long o01 = C4, o10 = (long)W * C4, o11 = (long)W * C4 + C4;
+        const f32x4 v00 = ld4<H>(x, base), v01 = ld4<H>(x, base + o01), v10 = ld4<H>(x, base + o10), v11 = ld4<H>(x, base + o11);
+        const f32x4 m = ld4<H>(y, i), g = ld4<H>(dy, i);
+        f32x4 g00, g01, g10, g11;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool a = v00[e] == m[e];
+            const bool bb = !a && v01[e] == m[e];
+            const bool cc = !a && !bb && v10[e] == m[e];
+            const bool dd = !a && !bb && !cc;
+            g00[e] = a ? g[e] : 0.f; g01[e] = bb ? g[e] : 0.f; g10[e] = cc ? g[e] : 0.f; g11[e] = dd ? g[e] : 0.f;
+        }
+        st4<H>(dx, base, g00); st4<H>(dx, base + o01, g01); st4<H>(dx, base + o10, g10); st4<H>(dx, base + o11, g11);
+    }
+}
+template <int H>
+__global__ void upsample16_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx, int B, int Hh, int W, int C4) {
+    const long n = (long)B * Hh * W * C4;      // Hh, W: low-res dims; dy is [B, 2H, 2W, C]
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4; long r = i / C4;
+        const int w = r % W; r /= W;
+        const int h = r % Hh; const int b = r / Hh;
+        const long base = (((long)b * 2 * Hh + 2 * h) * 2 * W + 2 * w) * C4 + c;
+        st4<H>(dx, i, ld4<H>(dy, base) + ld4<H>(dy, base + C4) + ld4<H>(dy, base + 2L * W * C4) + ld4<H>(dy, base + 2L * W * C4 + C4));
+    }
+}
+
+static inline int rows16(long M, int C) {
+    long nb = 1024 / (C / 64);
+    if (nb > 512) nb = 512;
+    const long maxb = (M + 63) / 64;
+    if (nb > maxb) nb = maxb;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+static inline int grid16(long n) {
+    long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+static inline bool hcode_ok(int h) { return h >= 0 && h <= 2; }
+// (hx, hy) pairs that occur: a tensor is fp32 or THE 16-bit type of the run
+#define DISPATCH_HH(hx, hy, LAUNCH)                                              \
+    do {                                                                         \
+        if (hx == 0 && hy == 0) { LAUNCH(0, 0); }                                \
+        else if (hx == 0 && hy == 1) { LAUNCH(0, 1); }                           \
+        else if (hx == 1 && hy == 1) { LAUNCH(1, 1); }                           \
+        else if (hx == 1 && hy == 0) { LAUNCH(1, 0); }                           \
+        else if (hx == 0 && hy == 2) { LAUNCH(0, 2); }                           \
+        else if (hx == 2 && hy == 2) { LAUNCH(2, 2); }                           \
+        else if (hx == 2 && hy == 0) { LAUNCH(2, 0); }                           \
+        else return (int)hipErrorInvalidValue;                                   \
+    } while (0)
+#define DISPATCH_H(h, LAUNCH)                                                    \
+    do {                                                                         \
+        if (h == 0) { LAUNCH(0); } else if (h == 1) { LAUNCH(1); } else if (h == 2) { LAUNCH(2); } \
+        else return (int)hipErrorInvalidValue;                                   \
+    } while (0)
+
+extern "C" {
+
+// workspace: mmseg_norm_workspace_floats(C) floats.  hx: element code of x (0 fp32, 1 bf16, 2 fp16)
+int mmseg_bn_stats_t(const void* x, const float* gamma, const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                     float* mov_mean, float* mov_var, float* ws, long M, int C, float eps, float momentum, int hx, void* stream) {
+    if ((C & 63) || !hcode_ok(hx)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = rows16(M, C);
+    const long rpb = (M + nblk - 1) / nblk;
+#define L(HX) hipLaunchKernelGGL((bn16_partial_kernel<0, HX, 0>), dim3(nblk, C / 64), dim3(256), 0, st, x, (const void*)nullptr, (const void*)nullptr, \
+                                 (const float*)nullptr, (const float*)nullptr, ws, M, C, rpb, 0);                                                       \
+              hipLaunchKernelGGL((bn16_stats_final_kernel<HX>), dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, x, gamma, beta, mean, invstd, \
+                                 scale, shift, mov_mean, mov_var, nblk, C, M, eps, momentum)
+    DISPATCH_H(hx, L);
+#undef L
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_bn_apply_t(const void* x, const float* scale, const float* shift, void* y, long M, int C, int relu, int hx, int hy, void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    const long n4 = M * (C / 4);
+#define L(HX, HY) hipLaunchKernelGGL((bn16_apply_kernel<HX, HY>), dim3(grid16(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, n4, C / 4, relu)
+    DISPATCH_HH(hx, hy, L);
+#undef L
+    return MMSEG_CHECK_LAUNCH();
+}
+// dy, y: element code hy; x, dx: element code hx.  dgamma / dbeta may be NULL (frozen).  coef: 3*C floats of scratch
+int mmseg_bn_bwd_t(const void* dy, const void* y, const void* x, const float* gamma, const float* mean, const float* invstd, void* dx,
+                   float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, int accumulate, int hx, int hy, void* stream) {
+    if (C & 63) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = rows16(M, C);
+    const long rpb = (M + nblk - 1) / nblk;
+    const long n4 = M * (C / 4);
+#define L(HX, HY) hipLaunchKernelGGL((bn16_partial_kernel<1, HX, HY>), dim3(nblk, C / 64), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu); \
+                  hipLaunchKernelGGL(bn16_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta,   \
+                                     coef, nblk, C, M, accumulate);                                                                                      \
+                  hipLaunchKernelGGL((bn16_bwd_apply_kernel<HX, HY>), dim3(grid16(n4)), dim3(256), 0, st, dy, y, x, (const float*)coef, dx, n4, C / 4, relu)
+    DISPATCH_HH(hx, hy, L);
+#undef L
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_maxpool2_fwd_t(const void* x, void* y, int B, int H, int W, int C, int h, void* stream) {
+    if ((C & 3) || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+    const long n = (long)B * (H / 2) * (W / 2) * (C / 4);
+#define L(HH) hipLaunchKernelGGL((maxpool16_fwd_kernel<HH>), dim3(grid16(n)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4)
+    DISPATCH_H(h, L);
+#undef L
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_maxpool2_bwd_t(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, int h, void* stream) {
+    if ((C & 3) || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+    const long n = (long)B * (H / 2) * (W / 2) * (C / 4);
+#define L(HH) hipLaunchKernelGGL((maxpool16_bwd_kernel<HH>), dim3(grid16(n)), dim3(256), 0, (hipStream_t)stream, x, y, dy, dx, B, H, W, C / 4)
+    DISPATCH_H(h, L);
+#undef L
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_upsample2_bwd_t(const void* dy, void* dx, int B, int H, int W, int C, int h, void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    const long n = (long)B * H * W * (C / 4);
+#define L(HH) hipLaunchKernelGGL((upsample16_bwd_kernel<HH>), dim3(grid16(n)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C / 4)
+    DISPATCH_H(h, L);
+#undef L
+    return MMSEG_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -46,6 +46,9 @@ struct ConvParams {
     // output pixel mapping (fast path): launch pixel (b, ho, wo) is stored at (b, ho*osh + ooh, wo*osw + oow) of a
     // [B, oH, oW, Cout] tensor.  Identity unless the launch is one parity class of a strided data gradient.
     int oH, oW, osh, osw, ooh, oow;
+    // 16-bit tensors in HBM (reduced-precision modes only; the `_t` entry points): bit 0 = x1, bit 1 = x2, bit 2 = y / y2 are stored in
+    // the 16-bit type of the active precision mode, bit 3 = that type is fp16 (else bf16).  0 = all fp32.
+    int io;
 };
 
 #define BK 32
@@ -271,6 +274,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvParams p) {
                 const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= p.M) continue;
                 const float v = act_apply(acc[i][j][r] * sv + bv, p.act, p.alpha);
+                if (p.io & 4) {                  // 16-bit output tensor (fp32 arithmetic; the generic kernel only WRITES 16-bit)
+                    const size_t o = p.y2 == nullptr ? (size_t)m * p.Cout + n
+                                     : (n < p.nsplit1 ? (size_t)m * p.nsplit1 + n : (size_t)m * (p.Cout - p.nsplit1) + (n - p.nsplit1));
+                    void* base = (p.y2 == nullptr || n < p.nsplit1) ? (void*)p.y : (void*)p.y2;
+                    if (p.io & 8) reinterpret_cast<_Float16*>(base)[o] = (_Float16)v;
+                    else reinterpret_cast<__bf16*>(base)[o] = (__bf16)v;
+                    continue;
+                }
                 if (p.y2 == nullptr) p.y[(size_t)m * p.Cout + n] = v;
                 else if (n < p.nsplit1) p.y[(size_t)m * p.nsplit1 + n] = v;
                 else p.y2[(size_t)m * (p.Cout - p.nsplit1) + (n - p.nsplit1)] = v;
@@ -345,9 +356,11 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
         return tile2d ? (t_b * p.Ho + t_y0 + (row >> 4)) * p.Wo + t_x0 + (row & 15) : m0 + row;
     };
 
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 4, 0x00020000);
+    // element size of the two inputs (2 when the tensor is stored in the 16-bit type: reduced-precision modes, ConvParams::io)
+    const int es1 = (BF16 && (p.io & 1)) ? 2 : 4, es2 = (BF16 && (p.io & 2)) ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * es1, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
-                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * 4 : 0, 0x00020000);
+                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * es2 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.K * p.Cout * 4, 0x00020000);
 
     // ---- per-thread row state: element offsets of (b, hb, wb, 4*kc) in x1 / x2 ------------------------------
@@ -378,18 +391,29 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
         b_o[j] = (row < BN && n < p.Cout) ? n * p.K + 4 * kc : -1;
     }
 
-    f32x4 ra[A_F4], rb[B_F4];
+    u32x4 ra[A_F4];         // the A tile in flight as raw bits: 4 floats, or 4 16-bit elements in the first two dwords (ld16)
+    f32x4 rb[B_F4];
+    bool ld16 = false;
+    // 4 consecutive channels at element offset `off` of a tensor with `es`-byte elements; out of range -> zeros
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int off, bool ok, int es) -> u32x4 {
+        if (BF16 && es == 2) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, ok ? off * 2 : BUF_OOB, 0, 0);
+            return u32x4{v[0], v[1], 0u, 0u};
+        }
+        return __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off * 4 : BUF_OOB, 0, 0);
+    };
     auto load_tile = [&]() {
         const int kh = s_kh, kw = s_kw;
         const int b_koff = (kh * p.KW + kw) * Cin + s_c0;                  // first K column of the tile
         if (s_c0 < p.C1) {
+            ld16 = es1 == 2;
             if (p.ups) {
 #pragma unroll
                 for (int j = 0; j < A_F4; ++j) {
                     const int hi = a_hb[j] + kh, wi = a_wb[j] + kw;
                     const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                     const int off = ((a_o1[j] + (hi >> 1)) * p.W1 + (wi >> 1)) * p.C1 + s_c0 + 4 * kc;
-                    ra[j] = buf_load4(r1, ok ? off * 4 : BUF_OOB);
+                    ra[j] = ld4(r1, off, ok, es1);
                 }
             } else {
                 const int toff = (kh * p.W + kw) * p.C1 + s_c0;
@@ -397,16 +421,17 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
                 for (int j = 0; j < A_F4; ++j) {
                     const int hi = a_hb[j] + kh, wi = a_wb[j] + kw;
                     const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                    ra[j] = buf_load4(r1, ok ? (a_o1[j] + toff) * 4 : BUF_OOB);
+                    ra[j] = ld4(r1, a_o1[j] + toff, ok, es1);
                 }
             }
         } else {
+            ld16 = es2 == 2;
             const int toff = (kh * p.W + kw) * p.C2 + (s_c0 - p.C1);
 #pragma unroll
             for (int j = 0; j < A_F4; ++j) {
                 const int hi = a_hb[j] + kh, wi = a_wb[j] + kw;
                 const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                ra[j] = buf_load4(r2, ok ? (a_o2[j] + toff) * 4 : BUF_OOB);
+                ra[j] = ld4(r2, a_o2[j] + toff, ok, es2);
             }
         }
 #pragma unroll
@@ -423,8 +448,15 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
 #pragma unroll
             for (int j = 0; j < A_F4; ++j) {
                 const int row = ar0 + j * A_RPP;
-                LV4 v = {(LT)ra[j][0], (LT)ra[j][1], (LT)ra[j][2], (LT)ra[j][3]};
-                *reinterpret_cast<LV4*>(&A[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)]) = v;
+                float* dst = &A[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)];
+                if (ld16) {                      // already the MFMA operand type: the 8 bytes go to LDS as they are
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{ra[j][0], ra[j][1]};
+                } else {
+                    const f32x4 f = __builtin_bit_cast(f32x4, ra[j]);
+                    LV4 v = {(LT)f[0], (LT)f[1], (LT)f[2], (LT)f[3]};
+                    *reinterpret_cast<LV4*>(dst) = v;
+                }
             }
 #pragma unroll
             for (int j = 0; j < B_F4; ++j) {
@@ -435,7 +467,7 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
         } else {
 #pragma unroll
             for (int j = 0; j < A_F4; ++j)
-                *reinterpret_cast<f32x4*>(&A[(ar0 + j * A_RPP) * LD + 4 * (kc ^ (((ar0 + j * A_RPP) >> 1) & 7))]) = ra[j];
+                *reinterpret_cast<u32x4*>(&A[(ar0 + j * A_RPP) * LD + 4 * (kc ^ (((ar0 + j * A_RPP) >> 1) & 7))]) = ra[j];
 #pragma unroll
             for (int j = 0; j < B_F4; ++j) {
                 const int row = ar0 + j * A_RPP;
@@ -532,6 +564,14 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
                     m = (ob * p.oH + oh * p.osh + p.ooh) * p.oW + ow * p.osw + p.oow;
                 }
                 const float v = act_apply(acc[0][i][j][r] * sv + bv, p.act, p.alpha);
+                if (BF16 && (p.io & 4)) {        // 16-bit output tensor(s)
+                    LT* y = reinterpret_cast<LT*>(p.y);
+                    LT* y2 = reinterpret_cast<LT*>(p.y2);
+                    if (p.y2 == nullptr) y[(size_t)m * p.Cout + n] = (LT)v;
+                    else if (n < p.nsplit1) y[(size_t)m * p.nsplit1 + n] = (LT)v;
+                    else y2[(size_t)m * (p.Cout - p.nsplit1) + (n - p.nsplit1)] = (LT)v;
+                    continue;
+                }
                 if (p.y2 == nullptr) p.y[(size_t)m * p.Cout + n] = v;
                 else if (n < p.nsplit1) p.y[(size_t)m * p.nsplit1 + n] = v;
                 else p.y2[(size_t)m * (p.Cout - p.nsplit1) + (n - p.nsplit1)] = v;
@@ -657,7 +697,7 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (p.M <= 0 || p.Cout <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
     if (p.C1 == 8 && p.C2 == 0 && p.Cout == 8 && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.transposed && !p.ups &&
         p.Ho == p.H && p.Wo == p.W && p.pad_h == 1 && p.pad_w == 1 && p.y2 == nullptr && p.w != nullptr && p.osh == 1 &&
-        p.oscale == nullptr && aligned16(p.x1) && aligned16(p.y) && (long)p.M * 8 * 4 < (1L << 31) - 64) {
+        p.oscale == nullptr && aligned16(p.x1) && aligned16(p.y) && (long)p.M * 8 * 4 < (1L << 31) - 64 && p.io == 0) {
         hipLaunchKernelGGL((conv_direct_kernel<8, 8, 3>), dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st,
                            p.x1, p.w, p.bias, p.y, p.B, p.H, p.W, 1, p.act, p.alpha);
         MMSEG_SET_LAST(3, 8, 8);
@@ -671,6 +711,7 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
                       (long)p.K * p.Cout * 4 < lim;
     const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
     if (omap && !fast) return (int)hipErrorInvalidValue;     // strided output mapping exists on the fast path only
+    if (!fast && (p.io & 3)) return (int)hipErrorInvalidValue;       // only the fast path reads 16-bit input tensors
     if (!fast && p.w == nullptr) return (int)hipErrorInvalidValue;   // the generic kernels read the Keras-layout weights: a caller
                                                                      // that only prepared `wt` must not fall through to them
     if (fast) {
@@ -1227,10 +1268,37 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
     const int pbeg = bz * q.chunk;                       // multiple of 32
     const int pend = min(p.M, pbeg + q.chunk);
 
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 4, 0x00020000);
+    // 16-bit tensors in HBM (reduced-precision modes, mmseg_conv2d_wgrad_t): io bit 0 = x1 AND x2, bit 2 = dy hold elements of the
+    // MFMA operand type -- they go to LDS without conversion
+    const bool x16 = LP && (p.io & 1), d16 = LP && (p.io & 4);
+    const int esx = x16 ? 2 : 4, esd = d16 ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * esx, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(TWO ? p.x2 : p.x1), 0,
-                                                                        TWO ? p.B * p.H * p.W * p.C2 * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)q.dy, 0, p.M * p.Cout * 4, 0x00020000);
+                                                                        TWO ? p.B * p.H * p.W * p.C2 * esx : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)q.dy, 0, p.M * p.Cout * esd, 0x00020000);
+    // 4 consecutive channels at element offset `off`: raw bits (4 floats, or 4 16-bit elements in the first two dwords)
+    auto ldraw = [&](const __amdgpu_buffer_rsrc_t& r, int off, bool ok, bool h) -> u32x4 {
+        if (LP && h) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, ok ? off * 2 : BUF_OOB, 0, 0);
+            return u32x4{v[0], v[1], 0u, 0u};
+        }
+        return __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off * 4 : BUF_OOB, 0, 0);
+    };
+    // element e (0..3) of each of 4 raw pixel loads -> the 4 values of one LDS row segment, as the 16-bit operand type
+    auto row16 = [&](const u32x4 (&px)[4], int e, bool h) -> LV4 {
+        if constexpr (LP) {
+            if (h) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const int w = e >> 1, sh = 16 * (e & 1);
+                const unsigned a0 = (px[0][w] >> sh) & 0xffffu, a1 = (px[1][w] >> sh) & 0xffffu;
+                const unsigned a2 = (px[2][w] >> sh) & 0xffffu, a3 = (px[3][w] >> sh) & 0xffffu;
+                return __builtin_bit_cast(LV4, u32x2{a0 | (a1 << 16), a2 | (a3 << 16)});
+            }
+        }
+        const f32x4 f0 = __builtin_bit_cast(f32x4, px[0]), f1 = __builtin_bit_cast(f32x4, px[1]);
+        const f32x4 f2 = __builtin_bit_cast(f32x4, px[2]), f3 = __builtin_bit_cast(f32x4, px[3]);
+        return LV4{(LT)f0[e], (LT)f1[e], (LT)f2[e], (LT)f3[e]};
+    };
 
     // ---- A side: this thread's (k quad, pixel group) blocks.  Tap, channel and source tensor are fixed per thread, so the
     // gather offset is  b * sb + (hi >> sh) * sr + (wi >> sh) * sp + c  with per-thread strides -- no branches in the loop ----
@@ -1272,7 +1340,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
         d_off[it] = (pbeg + 4 * pg) * p.Cout + n0 + 4 * cq;
     }
 
-    f32x4 ra[A_IT][4], rdv[D_IT][4];
+    u32x4 ra[A_IT][4], rdv[D_IT][4];
     auto load_stage = [&](int ps) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
@@ -1284,10 +1352,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
             for (int j = 0; j < 4; ++j) {
                 const int wi = wi0 + j * p.stride;
                 const bool ok = rowok && (unsigned)wi < (unsigned)p.W;
-                const int off = (rowoff + (wi >> a_sh[it]) * a_sp[it]) * 4;
-                // descriptors stay wave-uniform: with two inputs both loads are issued, the unselected one out of range (zeros)
-                if constexpr (!TWO) ra[it][j] = buf_load4(r1, ok ? off : BUF_OOB);
-                else ra[it][j] = buf_load4(r1, (ok && a_from1[it]) ? off : BUF_OOB) + buf_load4(r2, (ok && !a_from1[it]) ? off : BUF_OOB);
+                const int off = rowoff + (wi >> a_sh[it]) * a_sp[it];
+                // descriptors stay wave-uniform: with two inputs both loads are issued, the unselected one out of range (zero bits)
+                if constexpr (!TWO) ra[it][j] = ldraw(r1, off, ok, x16);
+                else ra[it][j] = ldraw(r1, off, ok && a_from1[it], x16) | ldraw(r2, off, ok && !a_from1[it], x16);
             }
             // advance the pixel group by one stage (32 pixels): q32 rows + r32 columns, one carry; the host guarantees Ho > q32
             a_wo[it] += r32; a_ho[it] += q32;
@@ -1299,7 +1367,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
             const int m0 = ps + 4 * d_pg[it];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                rdv[it][j] = buf_load4(rd, (d_ok[it] && m0 + j < pend) ? (d_off[it] + j * p.Cout) * 4 : BUF_OOB);
+                rdv[it][j] = ldraw(rd, d_off[it] + j * p.Cout, d_ok[it] && m0 + j < pend, d16);
             d_off[it] += PT * p.Cout;
         }
     };
@@ -1313,11 +1381,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
             for (int e = 0; e < 4; ++e) {
                 const int row = a_row[it] + e;
                 if constexpr (LP) {
-                    LV4 v = {(LT)ra[it][0][e], (LT)ra[it][1][e], (LT)ra[it][2][e], (LT)ra[it][3][e]};
-                    *reinterpret_cast<LV4*>(&A[row * LD + 4 * ((a_pg[it] >> 1) ^ ((row >> 1) & 3)) + 2 * (a_pg[it] & 1)]) = v;
+                    *reinterpret_cast<LV4*>(&A[row * LD + 4 * ((a_pg[it] >> 1) ^ ((row >> 1) & 3)) + 2 * (a_pg[it] & 1)]) = row16(ra[it], e, x16);
                 } else {
-                    const f32x4 v = {ra[it][0][e], ra[it][1][e], ra[it][2][e], ra[it][3][e]};
-                    *reinterpret_cast<f32x4*>(&A[row * LD + 4 * (a_pg[it] ^ wg_swz(row))]) = v;
+                    const u32x4 v = {ra[it][0][e], ra[it][1][e], ra[it][2][e], ra[it][3][e]};
+                    *reinterpret_cast<u32x4*>(&A[row * LD + 4 * (a_pg[it] ^ wg_swz(row))]) = v;
                 }
             }
         }
@@ -1328,11 +1395,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
             for (int e = 0; e < 4; ++e) {
                 const int row = d_row[it] + e;
                 if constexpr (LP) {
-                    LV4 v = {(LT)rdv[it][0][e], (LT)rdv[it][1][e], (LT)rdv[it][2][e], (LT)rdv[it][3][e]};
-                    *reinterpret_cast<LV4*>(&D[row * LD + 4 * ((d_pg[it] >> 1) ^ ((row >> 1) & 3)) + 2 * (d_pg[it] & 1)]) = v;
+                    *reinterpret_cast<LV4*>(&D[row * LD + 4 * ((d_pg[it] >> 1) ^ ((row >> 1) & 3)) + 2 * (d_pg[it] & 1)]) = row16(rdv[it], e, d16);
                 } else {
-                    const f32x4 v = {rdv[it][0][e], rdv[it][1][e], rdv[it][2][e], rdv[it][3][e]};
-                    *reinterpret_cast<f32x4*>(&D[row * LD + 4 * (d_pg[it] ^ wg_swz(row))]) = v;
+                    const u32x4 v = {rdv[it][0][e], rdv[it][1][e], rdv[it][2][e], rdv[it][3][e]};
+                    *reinterpret_cast<u32x4*>(&D[row * LD + 4 * (d_pg[it] ^ wg_swz(row))]) = v;
                 }
             }
         }
@@ -1547,7 +1613,7 @@ static int conv2d_fwd_impl(const float* x1, const float* x2, const float* w, con
                            float* y, float* y2,
                            int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                            int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1,
-                           int oH, int oW, int osh, int osw, int ooh, int oow, void* stream) {
+                           int oH, int oW, int osh, int osw, int ooh, int oow, void* stream, int io = 0) {
     ConvParams p;
     p.oH = oH; p.oW = oW; p.osh = osh; p.osw = osw; p.ooh = ooh; p.oow = oow;
     p.x1 = x1; p.x2 = x2; p.w = w; p.wt = wt; p.bias = bias; p.oscale = oscale; p.y = y; p.y2 = y2;
@@ -1556,6 +1622,9 @@ static int conv2d_fwd_impl(const float* x1, const float* x2, const float* w, con
     p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
     p.pad_h = pad_h; p.pad_w = pad_w; p.ups = ups; p.transposed = transposed; p.act = act; p.alpha = alpha;
     p.M = B * Ho * Wo; p.K = KH * KW * (C1 + C2); p.nsplit1 = nsplit1;
+    p.io = io;
+    if (io != 0 && g_conv_bf16 == 0) return (int)hipErrorInvalidValue;      // 16-bit tensors exist in the reduced-precision modes only
+    if (io != 0 && g_conv_bf16 == 2) p.io |= 8;
     if (ups && ((H & 1) || (W & 1))) return (int)hipErrorInvalidValue;
     if (C2 > 0 && x2 == nullptr) return (int)hipErrorInvalidValue;
     if ((long)B * Ho * Wo >= (1L << 31)) return (int)hipErrorInvalidValue;
@@ -1576,6 +1645,21 @@ int mmseg_conv2d_fwd_scaled(const float* x1, const float* x2, const float* w, co
                             int pad_h, int pad_w, int ups, int act, float alpha, void* stream) {
     return conv2d_fwd_impl(x1, x2, w, wt, bias, oscale, y, nullptr, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad_h, pad_w, ups,
                            0, act, alpha, 0, Ho, Wo, 1, 1, 0, 0, stream);
+}
+// The same two entry points with 16-bit tensors in HBM (reduced-precision modes: mmseg_set_conv_precision(1 | 2) selects bf16 |
+// fp16): io bit 0 = x1, bit 1 = x2 are 16-bit (MFMA fast path only: Cin % 32 == 0), bit 2 = y (and y2) is written 16-bit.
+// Arithmetic as before (16-bit MFMA operands, fp32 accumulation, fp32 bias / scale / activation).
+int mmseg_conv2d_fwd_t(const void* x1, const void* x2, const float* w, const float* wt, const float* bias, void* y, void* y2,
+                       int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                       int pad_h, int pad_w, int ups, int transposed, int act, float alpha, int nsplit1, int io, void* stream) {
+    return conv2d_fwd_impl((const float*)x1, (const float*)x2, w, wt, bias, nullptr, (float*)y, (float*)y2, B, H, W, C1, C2, Ho, Wo, Cout,
+                           KH, KW, stride, pad_h, pad_w, ups, transposed, act, alpha, nsplit1, Ho, Wo, 1, 1, 0, 0, stream, io & 7);
+}
+int mmseg_conv2d_fwd_scaled_t(const void* x1, const void* x2, const float* w, const float* wt, const float* bias, const float* oscale,
+                              void* y, int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                              int pad_h, int pad_w, int ups, int act, float alpha, int io, void* stream) {
+    return conv2d_fwd_impl((const float*)x1, (const float*)x2, w, wt, bias, oscale, (float*)y, nullptr, B, H, W, C1, C2, Ho, Wo, Cout,
+                           KH, KW, stride, pad_h, pad_w, ups, 0, act, alpha, 0, Ho, Wo, 1, 1, 0, 0, stream, io & 7);
 }
 // One parity class (ph, pw) of the data gradient of a stride-s convolution (s = 2), exact taps only:
 //   dx[b, s*i + ph, s*j + pw, :] = sum_{a,b2} dy[b, i - a, j - b2, :] . W[ph + s*a, pw + s*b2, :, :]^T
@@ -1627,7 +1711,7 @@ int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* d
                 p.B = B; p.H = Ho; p.W = Wo; p.C1 = Cout; p.C2 = 0; p.H1 = Ho; p.W1 = Wo;
                 p.Ho = Hs; p.Wo = Ws; p.Cout = Cin; p.KH = TH; p.KW = TW; p.stride = 1;
                 p.pad_h = TH - 1; p.pad_w = TW - 1; p.ups = 0; p.transposed = 0; p.act = 0; p.alpha = 0.f;
-                p.M = B * Hs * Ws; p.K = TH * TW * Cout; p.nsplit1 = 0;
+                p.M = B * Hs * Ws; p.K = TH * TW * Cout; p.nsplit1 = 0; p.io = 0;
                 if (p.M > maxM) maxM = p.M;
                 if (((uintptr_t)p.wt & 15) != 0) return (int)hipErrorInvalidValue;
             }
@@ -1721,9 +1805,26 @@ long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int 
     return need;
 }
 
+static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
+                             int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                             int pad_h, int pad_w, int ups, int accumulate, void* stream, int io);
 int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
                        int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                        int pad_h, int pad_w, int ups, int accumulate, void* stream) {
+    return conv2d_wgrad_impl(x1, x2, dy, dw, ws, ws_floats, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad_h, pad_w, ups, accumulate,
+                             stream, 0);
+}
+// The same with 16-bit operands in HBM (reduced-precision modes; transposed-staging kernel only, i.e. stride 1 and Wo % 4 == 0): io bit 0 =
+// x1 (and x2) are 16-bit, bit 2 = dy is 16-bit.  dw and the slabs stay fp32.
+int mmseg_conv2d_wgrad_t(const void* x1, const void* x2, const void* dy, float* dw, float* ws, long ws_floats,
+                         int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                         int pad_h, int pad_w, int ups, int accumulate, int io, void* stream) {
+    return conv2d_wgrad_impl((const float*)x1, (const float*)x2, (const float*)dy, dw, ws, ws_floats, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
+                             stride, pad_h, pad_w, ups, accumulate, stream, io & 5);
+}
+static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, float* dw, float* ws, long ws_floats,
+                             int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
+                             int pad_h, int pad_w, int ups, int accumulate, void* stream, int io) {
     WgradParams q;
     ConvParams& p = q.c;
     p.x1 = x1; p.x2 = x2; p.w = nullptr; p.wt = nullptr; p.bias = nullptr; p.oscale = nullptr; p.y = nullptr; p.y2 = nullptr;
@@ -1731,9 +1832,10 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
     p.H1 = ups ? H / 2 : H; p.W1 = ups ? W / 2 : W;
     p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
     p.pad_h = pad_h; p.pad_w = pad_w; p.ups = ups; p.transposed = 0; p.act = 0; p.alpha = 0.f;
-    p.M = B * Ho * Wo; p.K = KH * KW * (C1 + C2); p.nsplit1 = 0;
+    p.M = B * Ho * Wo; p.K = KH * KW * (C1 + C2); p.nsplit1 = 0; p.io = io;
     p.oH = Ho; p.oW = Wo; p.osh = 1; p.osw = 1; p.ooh = 0; p.oow = 0;
     if (p.M <= 0 || p.K <= 0 || Cout <= 0) return (int)hipErrorInvalidValue;
+    if (io != 0 && g_conv_bf16 == 0) return (int)hipErrorInvalidValue;
     const long need = mmseg_conv2d_wgrad_workspace(B, Ho, Wo, C1 + C2, Cout, KH, KW);
     if (need > ws_floats) return (int)hipErrorInvalidValue;
     const long KN = (long)p.K * Cout;
@@ -1751,6 +1853,7 @@ int mmseg_conv2d_wgrad(const float* x1, const float* x2, const float* dy, float*
         chunk = (p.M + S - 1) / S;
         chunk = (chunk + 31) / 32 * 32;
     }
+    if (io != 0 && !tr) return (int)hipErrorInvalidValue;          // only the transposed-staging kernel reads 16-bit operands
     if (wgrad_ws_floats(S, KN) > ws_floats) return (int)hipErrorInvalidValue;
     float* tmp = (S > 64) ? ws + (size_t)S * KN : nullptr;
     const bool direct = S == 1 && !accumulate;      // a single slab that overwrites dW needs no staging

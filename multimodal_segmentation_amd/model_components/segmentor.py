@@ -20,7 +20,7 @@ class Segmentor(nn.Model):
 
     def forward(self, s, training=False):
         l = nn.conv_bn(self, 'c0', 'c0_bn', s, training, relu=True)
-        l = nn.conv_bn(self, 'c1', 'c1_bn', l, training, relu=True)
+        l = nn.conv_bn(self, 'c1', 'c1_bn', l, training, relu=True, y16=False)      # the 1x1 head (5 outputs) reads fp32
         self.last_logits = nn.conv(self, 'out', l)
         return ops.softmax(self.last_logits)
 

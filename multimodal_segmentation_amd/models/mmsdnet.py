@@ -50,6 +50,8 @@ class MMSDNet(BaseNet):
         convolutions on operands rounded to that type with fp32 accumulation (BASELINE configs #3 / #5: reduced-
         precision compute, fp32 master weights, fp32 gradient all-reduce).  Process-wide switch of the kernel library."""
         ops.set_conv_precision(self.conf.get('compute_dtype', 'fp32'))
+        # conf.act_storage (build-defined, default 'fp32'): 'half' keeps the trunk's activations / gradients in HBM in the 16-bit type
+        ops.set_activation_storage(self.conf.get('act_storage', 'fp32') == 'half')
         # conf.sync_bn (build-defined, default False): BatchNorm batch statistics over all data-parallel ranks (parallel/dp.py)
         from ..parallel import dp
         dp.set_sync_bn(self.conf.get('sync_bn', False))

@@ -302,7 +302,7 @@ def bn_params(m, name, c):
     m.add_param(name + '/moving_variance', (c,), 'ones', trainable=False)
 
 
-def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False, bias_grad=True):
+def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False, bias_grad=True, out_dtype=torch.float32):
     """bias_grad=False: the convolution feeds a training-mode BatchNorm, whose backward output sums to zero over
     (N,H,W) per channel, so the bias gradient is EXACTLY zero in exact arithmetic (the reference accumulates only
     rounding noise there); the column-sum pass over the gradient tensor is skipped and the bias keeps its value."""
@@ -310,7 +310,7 @@ def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, ups
     b = m.params.get(name + '/bias')
     return ops.conv2d(x, w.data, b.data if b is not None else None, stride, padding, act, alpha, x2, upsample,
                       wgrad=w.g(), bgrad=b.g() if (b is not None and bias_grad) else None, anchor=anchor(x.device),
-                      wkey=id(w))
+                      wkey=id(w), out_dtype=out_dtype)
 
 
 def dense(m, name, x, act=None, alpha=0.0):
@@ -318,24 +318,34 @@ def dense(m, name, x, act=None, alpha=0.0):
     return ops.dense(x, w.data, b.data, act, alpha, wgrad=w.g(), bgrad=b.g(), anchor=anchor(x.device))
 
 
-def bn(m, name, x, training, relu=False):
+def bn(m, name, x, training, relu=False, out_dtype=torch.float32):
     g, b = m.params[name + '/gamma'], m.params[name + '/beta']
     return ops.batchnorm(x, g.data, b.data, m.params[name + '/moving_mean'].data,
                          m.params[name + '/moving_variance'].data, training, relu,
-                         ggrad=g.g(), bgrad=b.g(), anchor=anchor(x.device))
+                         ggrad=g.g(), bgrad=b.g(), anchor=anchor(x.device), out_dtype=out_dtype)
 
 
-def conv_bn(m, cname, bname, x, training, relu=False, x2=None, upsample=False):
+def conv_bn(m, cname, bname, x, training, relu=False, x2=None, upsample=False, y16=True):
     """Conv2D(3x3 'same') -> BatchNormalization [-> ReLU].  Training: the two layers as separate launches (batch statistics
     need the whole convolution output first).  Inference without a tape (`predict`): one launch, BatchNorm folded into
-    the convolution epilogue."""
-    if training or torch.is_grad_enabled():
-        l = conv(m, cname, x, x2=x2, upsample=upsample, bias_grad=not training)
-        return bn(m, bname, l, training, relu=relu)
+    the convolution epilogue.
+    With 16-bit activation storage on (conf.act_storage = 'half', ops.set_activation_storage): the convolution output is stored in the
+    16-bit type when the convolution runs on the MFMA fast path (input channels a multiple of 32), the BatchNorm output when the
+    caller allows it (`y16`: its consumers read 16-bit tensors) and the channel count is a multiple of 64."""
     w, b = m.params[cname + '/kernel'], m.params.get(cname + '/bias')
+    half = ops.act16_dtype()
+    Cout = w.shape[3]
+    c1 = x.shape[3]
+    c2 = x2.shape[3] if x2 is not None else 0
+    conv_dt = half if (half is not None and c1 % 32 == 0 and c2 % 32 == 0 and Cout % 64 == 0) else torch.float32
+    bn_dt = half if (half is not None and y16 and Cout % 64 == 0) else torch.float32
+    if training or torch.is_grad_enabled():
+        l = conv(m, cname, x, x2=x2, upsample=upsample, bias_grad=not training, out_dtype=conv_dt)
+        return bn(m, bname, l, training, relu=relu, out_dtype=bn_dt)
     return ops.conv2d_bn_infer(x, w.data, b.data if b is not None else None, m.params[bname + '/gamma'].data,
                                m.params[bname + '/beta'].data, m.params[bname + '/moving_mean'].data,
-                               m.params[bname + '/moving_variance'].data, relu=relu, x2=x2, upsample=upsample, wkey=id(w))
+                               m.params[bname + '/moving_variance'].data, relu=relu, x2=x2, upsample=upsample, wkey=id(w),
+                               out_dtype=bn_dt)
 
 
 def norm_params(m, name, c, norm):

@@ -30,8 +30,38 @@ def _ws(tag, nfloats, device):
     return buf
 
 
-def _new(shape, like):
-    return torch.empty(shape, dtype=torch.float32, device=like.device)
+def _new(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ---- reduced-precision STORAGE of the convolutional trunk (build-defined; BASELINE configs #3 / #5) ------------------------------
+_act16 = [None]      # torch.bfloat16 / torch.float16 while 16-bit activation storage is on, else None
+_HCODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def set_activation_storage(on):
+    """conf.act_storage = 'half': the activations and gradients of the MFMA trunk (UNet conv - BatchNorm - ReLU chains incl. pooling,
+    up-sampling and skips; the segmentor's first block) live in HBM in the 16-bit type of the active precision mode.  Master
+    weights, weight gradients, statistics, softmax / rounding, losses, Adam and the all-reduce stay fp32.  Needs
+    set_conv_precision('bf16' | 'fp16') first.  Returns the previous setting."""
+    old = _act16[0]
+    if not on:
+        _act16[0] = None
+        return old is not None
+    mode = N.call('mmseg_get_conv_precision')
+    if mode == 0:
+        raise ValueError("16-bit activation storage needs compute_dtype 'bf16' or 'fp16'")
+    _act16[0] = torch.bfloat16 if mode == 1 else torch.float16
+    return old is not None
+
+
+def act16_dtype():
+    return _act16[0]
+
+
+def _h(t):
+    """element code of a tensor for the `_t` entry points: 0 fp32, 1 bf16, 2 fp16"""
+    return 0 if t is None else _HCODE[t.dtype]
 
 
 def _c(t):
@@ -130,6 +160,12 @@ def _conv_fwd_raw(x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH,
         assert y.numel() == B * Ho * Wo * Cout
     else:
         assert y.numel() == B * Ho * Wo * nsplit1 and y2.numel() == B * Ho * Wo * (Cout - nsplit1)
+    io = (1 if _h(x1) else 0) | (2 if _h(x2) else 0) | (4 if _h(y) else 0)
+    if io:      # 16-bit tensors in HBM (reduced-precision storage)
+        assert y2 is None or _h(y2) == _h(y)
+        N.call('mmseg_conv2d_fwd_t', x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw,
+               ups, transposed, act, float(alpha), nsplit1, io)
+        return
     N.call('mmseg_conv2d_fwd', x1, x2, w, wt, bias, y, y2, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw,
            ups, transposed, act, float(alpha), nsplit1)
 
@@ -156,7 +192,7 @@ class _Conv2d(torch.autograd.Function):
     are accumulated into `wgrad` / `bgrad` (views of the owner's gradient arena) instead of being returned."""
 
     @staticmethod
-    def forward(ctx, x1, x2, anchor, w, bias, stride, padding, act, alpha, ups, wgrad, bgrad, wkey):
+    def forward(ctx, x1, x2, anchor, w, bias, stride, padding, act, alpha, ups, wgrad, bgrad, wkey, out_dtype=torch.float32):
         x1 = _c(x1)
         x2 = _c(x2) if x2 is not None else None
         B, H1, W1, C1 = x1.shape
@@ -167,8 +203,9 @@ class _Conv2d(torch.autograd.Function):
         KH, KW, Cin, Cout = w.shape
         assert Cin == C1 + C2, 'kernel expects %d input channels, got %d' % (Cin, C1 + C2)
         Ho, Wo, ph, pw = _conv_geometry(H, W, KH, KW, stride, padding)
-        y = _new((B, Ho, Wo, Cout), x1)
+        y = _new((B, Ho, Wo, Cout), x1, out_dtype)
         wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
+        assert not (ACT[act] and out_dtype != torch.float32), 'a fused activation needs an fp32 output (its backward kernel is fp32)'
         _conv_fwd_raw(x1, x2, w, wt, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,
                       ACT[act], alpha, 0)
         ctx.geom = (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), ACT[act], alpha)
@@ -193,19 +230,25 @@ class _Conv2d(torch.autograd.Function):
         M = B * Ho * Wo
         if ctx.bgrad is not None:
             ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', M, Cout), dy.device)
-            N.call('mmseg_colsum', g, ctx.bgrad, ws, M, Cout, 1.0, 1)
+            N.call('mmseg_colsum', g if _h(g) == 0 else g.float(), ctx.bgrad, ws, M, Cout, 1.0, 1)
         if ctx.wgrad is not None:
             need = N.call('mmseg_conv2d_wgrad_workspace', B, Ho, Wo, C1 + C2, Cout, KH, KW)
             ws = _ws('wgrad', need, dy.device)
             # accumulates straight into the gradient-arena view (the final slab reduction adds to it)
-            N.call('mmseg_conv2d_wgrad', x1, x2, g, ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
-                   stride, ph, pw, ups, 1)
+            if _h(x1) or _h(x2) or _h(g):       # 16-bit operands in HBM: the transposed-staging kernel reads them as they are
+                assert x2 is None or _h(x2) == _h(x1)
+                N.call('mmseg_conv2d_wgrad_t', x1, x2, g, ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
+                       stride, ph, pw, ups, 1, (1 if _h(x1) else 0) | (4 if _h(g) else 0))
+            else:
+                N.call('mmseg_conv2d_wgrad', x1, x2, g, ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
+                       stride, ph, pw, ups, 1)
         _grad_done(ctx.wgrad, ctx.bgrad)
         if need_x1 or (x2 is not None and need_x2):
             Cin = C1 + C2
             tr = 1 if stride > 1 else 0
-            d1 = _new((B, H, W, C1), dy)
-            d2 = _new((B, H, W, C2), dy) if C2 else None
+            d1 = _new((B, H, W, C1), dy, x1.dtype)          # a gradient is stored like its tensor
+            d2 = _new((B, H, W, C2), dy, x2.dtype) if C2 else None
+            assert d2 is None or d2.dtype == d1.dtype
             taps = [[N.call('mmseg_conv2d_parity_taps', k, stride, q) for q in range(stride)] for k in (KH, KW)] if tr else None
             if tr and stride == 2 and KH == 4 and KW == 4 and ph == 0 and pw == 0 and C2 == 0 and not ups and Cout == 64 and \
                     Cin in (1, 4) and N.call('mmseg_conv2d_fast_path', 64, 0, 64, 0):
@@ -237,15 +280,19 @@ class _Conv2d(torch.autograd.Function):
                 _conv_fwd_raw(g, None, wf, wt, None, d1, d2, B, Ho, Wo, Cout, 0, H, W, Cin, KH, KW, stride, KH - 1 - ph,
                               KW - 1 - pw, 0, tr, 0, 0.0, C1 if C2 else 0)
             if ups:
-                dx1 = _new((B, H // 2, W // 2, C1), dy)
-                N.call('mmseg_upsample2_bwd', d1, dx1, B, H // 2, W // 2, C1)
+                dx1 = _new((B, H // 2, W // 2, C1), dy, d1.dtype)
+                if _h(d1):
+                    N.call('mmseg_upsample2_bwd_t', d1, dx1, B, H // 2, W // 2, C1, _h(d1))
+                else:
+                    N.call('mmseg_upsample2_bwd', d1, dx1, B, H // 2, W // 2, C1)
             else:
                 dx1 = d1
             dx2 = d2
-        return (dx1, dx2) + (None,) * 11
+        return (dx1, dx2) + (None,) * 12
 
 
-def conv2d_bn_infer(x, w, cbias, gamma, beta, mov_mean, mov_var, relu=False, x2=None, upsample=False, wkey=None):
+def conv2d_bn_infer(x, w, cbias, gamma, beta, mov_mean, mov_var, relu=False, x2=None, upsample=False, wkey=None,
+                    out_dtype=torch.float32):
     """`predict` of Conv2D -> BatchNormalization [-> ReLU] as ONE launch: the moving statistics are folded into a
     per-channel scale and bias of the convolution epilogue (no tape: inference only)."""
     x1 = _c(x)
@@ -267,22 +314,27 @@ def conv2d_bn_infer(x, w, cbias, gamma, beta, mov_mean, mov_var, relu=False, x2=
         N.call('mmseg_bn_infer_fold', gamma, beta, mov_mean, mov_var, cbias, ss[0], ss[1], Cout, BN_EPS)
         if wkey is not None:
             _bnfold_cache[key] = ((_weight_version[0], _bn_state_version[0]), ss)
-    y = _new((B, Ho, Wo, Cout), x1)
+    y = _new((B, Ho, Wo, Cout), x1, out_dtype)
     wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
-    N.call('mmseg_conv2d_fwd_scaled', x1, x2, w, wt, ss[1], ss[0], y, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, 1, ph, pw,
-           int(bool(upsample)), ACT['relu' if relu else None], 0.0)
+    io = (1 if _h(x1) else 0) | (2 if _h(x2) else 0) | (4 if _h(y) else 0)
+    if io:
+        N.call('mmseg_conv2d_fwd_scaled_t', x1, x2, w, wt, ss[1], ss[0], y, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, 1, ph, pw,
+               int(bool(upsample)), ACT['relu' if relu else None], 0.0, io)
+    else:
+        N.call('mmseg_conv2d_fwd_scaled', x1, x2, w, wt, ss[1], ss[0], y, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, 1, ph, pw,
+               int(bool(upsample)), ACT['relu' if relu else None], 0.0)
     return y
 
 
 def conv2d(x, w, bias=None, stride=1, padding='same', act=None, alpha=0.0, x2=None, upsample=False,
-           wgrad=None, bgrad=None, anchor=None, wkey=None):
+           wgrad=None, bgrad=None, anchor=None, wkey=None, out_dtype=torch.float32):
     """keras Conv2D on NHWC (+ fused nearest x2 up-sampling of x, + fused channel concat with x2, + fused
     bias/activation epilogue).  `wgrad`/`bgrad`: gradient-arena views to accumulate into (None = frozen)."""
     if upsample and (x.shape[3] % 4 != 0):
         raise ValueError('fused up-sampling needs C % 4 == 0')
     if wgrad is None and bgrad is None:
         anchor = None
-    return _Conv2d.apply(x, x2, anchor, w, bias, stride, padding, act, alpha, bool(upsample), wgrad, bgrad, wkey)
+    return _Conv2d.apply(x, x2, anchor, w, bias, stride, padding, act, alpha, bool(upsample), wgrad, bgrad, wkey, out_dtype)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -290,7 +342,7 @@ def conv2d(x, w, bias=None, stride=1, padding='same', act=None, alpha=0.0, x2=No
 # ------------------------------------------------------------------------------------------------------
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, gamma, beta, mov_mean, mov_var, relu, ggrad, bgrad):
+    def forward(ctx, x, anchor, gamma, beta, mov_mean, mov_var, relu, ggrad, bgrad, out_dtype=torch.float32):
         _bn_state_version[0] += 1          # the moving statistics are about to change: folded inference parameters are stale
         x = _c(x)
         C = x.shape[-1]
@@ -298,6 +350,18 @@ class _BatchNormTrain(torch.autograd.Function):
         stats = _new((4, C), x)  # mean, invstd, scale, shift
         ws = _ws('norm', N.call('mmseg_norm_workspace_floats', C), x.device)
         ctx.sync = dp.sync_bn()
+        hx, hy = _h(x), _HCODE[out_dtype]
+        ctx.h = (hx, hy)
+        if hx or hy:       # 16-bit storage of the input and / or the output (csrc/act16.hip): same arithmetic, 8-byte accesses
+            assert not ctx.sync, 'sync_bn and 16-bit activation storage are not combined'
+            N.call('mmseg_bn_stats_t', x, gamma, beta, stats[0], stats[1], stats[2], stats[3], mov_mean, mov_var, ws, M, C,
+                   BN_EPS, BN_MOMENTUM, hx)
+            y = _new(x.shape, x, out_dtype)
+            N.call('mmseg_bn_apply_t', x, stats[2], stats[3], y, M, C, int(relu), hx, hy)
+            ctx.relu = bool(relu)
+            ctx.gamma, ctx.ggrad, ctx.bgrad = gamma, ggrad, bgrad
+            ctx.save_for_backward(x, y if relu else None, stats)
+            return y
         if ctx.sync:
             # statistics over the global batch: (mean, biased variance) of this rank's rows, gathered in rank order, combined
             local = _new((2, C), x)
@@ -321,9 +385,15 @@ class _BatchNormTrain(torch.autograd.Function):
         dy = _c(dy)
         C = x.shape[-1]
         M = x.numel() // C
-        dx = _new(x.shape, x)
+        dx = _new(x.shape, x, x.dtype)
         coef = _ws('bn_coef', 3 * C, x.device)
         ws = _ws('norm', N.call('mmseg_norm_workspace_floats', C), x.device)
+        if ctx.h != (0, 0):
+            assert (ctx.ggrad is None) == (ctx.bgrad is None), 'BatchNorm gamma and beta are trained or frozen together'
+            N.call('mmseg_bn_bwd_t', dy, y, x, ctx.gamma, stats[0], stats[1], dx, ctx.ggrad, ctx.bgrad, coef, ws, M, C, int(ctx.relu), 1,
+                   ctx.h[0], ctx.h[1])
+            _grad_done(ctx.ggrad, ctx.bgrad)
+            return (dx,) + (None,) * 9
         if ctx.sync:
             # sums of this rank -> dgamma / dbeta (averaged over ranks with the other weight gradients); sums over all ranks -> dx
             local = _new((2, C), x)
@@ -337,7 +407,7 @@ class _BatchNormTrain(torch.autograd.Function):
                 N.call('mmseg_bn_bwd_finish', local, glob, ctx.gamma, stats[0], stats[1], None, None, coef, C, M * dp.world_size(), 0)
             N.call('mmseg_bn_bwd_apply', dy, y, x, coef, dx, M, C, int(ctx.relu))
             _grad_done(ctx.ggrad, ctx.bgrad)
-            return (dx,) + (None,) * 8
+            return (dx,) + (None,) * 9
         if ctx.ggrad is not None and ctx.bgrad is not None:
             # the final reduction adds dgamma / dbeta straight into the gradient-arena views
             N.call('mmseg_bn_bwd', dy, y, x, ctx.gamma, stats[0], stats[1], dx, ctx.ggrad, ctx.bgrad, coef, ws, M, C, int(ctx.relu), 1)
@@ -350,23 +420,27 @@ class _BatchNormTrain(torch.autograd.Function):
             if ctx.bgrad is not None:
                 _accumulate(ctx.bgrad, dbeta)
         _grad_done(ctx.ggrad, ctx.bgrad)
-        return (dx,) + (None,) * 8
+        return (dx,) + (None,) * 9
 
 
-def batchnorm(x, gamma, beta, mov_mean, mov_var, training, relu=False, ggrad=None, bgrad=None, anchor=None):
+def batchnorm(x, gamma, beta, mov_mean, mov_var, training, relu=False, ggrad=None, bgrad=None, anchor=None,
+              out_dtype=torch.float32):
     """keras BatchNormalization(axis=-1) [+ ReLU].  training: batch statistics and in-place moving-average update
     (what `fit` does); otherwise the moving statistics (what `predict` does)."""
     if training:
         if ggrad is None and bgrad is None:
             anchor = None
-        return _BatchNormTrain.apply(x, anchor, gamma, beta, mov_mean, mov_var, relu, ggrad, bgrad)
+        return _BatchNormTrain.apply(x, anchor, gamma, beta, mov_mean, mov_var, relu, ggrad, bgrad, out_dtype)
     x = _c(x)
     C = x.shape[-1]
     M = x.numel() // C
     ss = _new((2, C), x)
     N.call('mmseg_bn_infer_prep', gamma, beta, mov_mean, mov_var, ss[0], ss[1], C, BN_EPS)
-    y = _new(x.shape, x)
-    N.call('mmseg_bn_apply', x, ss[0], ss[1], y, M, C, int(relu))
+    y = _new(x.shape, x, out_dtype)
+    if _h(x) or _h(y):
+        N.call('mmseg_bn_apply_t', x, ss[0], ss[1], y, M, C, int(relu), _h(x), _h(y))
+    else:
+        N.call('mmseg_bn_apply', x, ss[0], ss[1], y, M, C, int(relu))
     return y
 
 
@@ -378,8 +452,11 @@ class _MaxPool2(torch.autograd.Function):
     def forward(ctx, x):
         x = _c(x)
         B, H, W, C = x.shape
-        y = _new((B, H // 2, W // 2, C), x)
-        N.call('mmseg_maxpool2_fwd', x, y, B, H, W, C)
+        y = _new((B, H // 2, W // 2, C), x, x.dtype)
+        if _h(x):
+            N.call('mmseg_maxpool2_fwd_t', x, y, B, H, W, C, _h(x))
+        else:
+            N.call('mmseg_maxpool2_fwd', x, y, B, H, W, C)
         ctx.save_for_backward(x, y)
         return y
 
@@ -387,8 +464,11 @@ class _MaxPool2(torch.autograd.Function):
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
         B, H, W, C = x.shape
-        dx = _new(x.shape, x)
-        N.call('mmseg_maxpool2_bwd', x, y, _c(dy), dx, B, H, W, C)
+        dx = _new(x.shape, x, x.dtype)
+        if _h(x):
+            N.call('mmseg_maxpool2_bwd_t', x, y, _c(dy), dx, B, H, W, C, _h(x))
+        else:
+            N.call('mmseg_maxpool2_bwd', x, y, _c(dy), dx, B, H, W, C)
         return dx
 
 

@@ -1,0 +1,154 @@
+"""16-bit tensors in HBM (reduced-precision STORAGE, a build-defined extension for BASELINE configs #3 / #5): every `_t` entry
+point against the fp32-storage path of the same precision mode on inputs that are already representable in the 16-bit type.
+The 16-bit MFMA operands are then identical, the accumulation order is the same kernel's, so a 16-bit OUTPUT must be bit for bit
+the rounding of the fp32-storage output (and an fp32 output bit for bit the same)."""
+import numpy as np
+import pytest
+import torch
+
+from multimodal_segmentation_amd import _native as N, ops as P
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+@pytest.fixture(params=['bf16', 'fp16'])
+def mode(request):
+    prev = P.set_conv_precision(request.param)
+    yield (torch.bfloat16 if request.param == 'bf16' else torch.float16)
+    P.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize('B,H,C1,C2,Cout,ups,act', [(2, 32, 64, 0, 64, 0, 1), (2, 16, 128, 0, 64, 1, 0), (1, 32, 64, 64, 128, 0, 1),
+                                                    (2, 24, 64, 0, 8, 0, 0)])
+def test_conv_fwd_16bit_io(B, H, C1, C2, Cout, ups, act, mode):
+    k = 1 if Cout == 8 else 3
+    H1 = H // 2 if ups else H
+    x1 = rnd(B, H1, H1, C1, seed=1).to(mode).to(DEV)
+    x2 = rnd(B, H, H, C2, seed=2).to(mode).to(DEV) if C2 else None
+    Cin = C1 + C2
+    w = (rnd(k, k, Cin, Cout, seed=3) * 0.05).to(DEV)
+    b = rnd(Cout, seed=4).to(DEV)
+    wp = torch.empty(w.numel(), device=DEV)
+    N.call('mmseg_conv2d_wprep', w, wp, k, k, Cin, Cout, 0)
+    p = k // 2
+    # fp32-storage path of the same precision mode
+    y32 = torch.empty(B, H, H, Cout, device=DEV)
+    N.call('mmseg_conv2d_fwd', x1.float(), x2.float() if C2 else None, w, wp, b, y32, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, p, p, ups,
+           0, act, 0.0, 0)
+    for out16 in (True, False):
+        y = torch.empty(B, H, H, Cout, device=DEV, dtype=mode if out16 else torch.float32)
+        io = 1 | (2 if C2 else 0) | (4 if out16 else 0)
+        N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, p, p, ups, 0, act, 0.0, 0, io)
+        assert torch.equal(y, y32.to(mode) if out16 else y32), 'out16=%s' % out16
+    # mixed: fp32 inputs, 16-bit output
+    y = torch.empty(B, H, H, Cout, device=DEV, dtype=mode)
+    N.call('mmseg_conv2d_fwd_t', x1.float(), x2.float() if C2 else None, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, p, p, ups,
+           0, act, 0.0, 0, 4)
+    assert torch.equal(y, y32.to(mode))
+
+
+def test_generic_kernel_writes_16bit_and_refuses_16bit_inputs(mode):
+    B, H, Cin, Cout = 2, 20, 1, 64
+    x = rnd(B, H, H, Cin, seed=5).to(DEV)
+    w = (rnd(3, 3, Cin, Cout, seed=6) * 0.2).to(DEV)
+    y32 = torch.empty(B, H, H, Cout, device=DEV)
+    N.call('mmseg_conv2d_fwd', x, None, w, None, None, y32, None, B, H, H, Cin, 0, H, H, Cout, 3, 3, 1, 1, 1, 0, 0, 1, 0.0, 0)
+    y = torch.empty(B, H, H, Cout, device=DEV, dtype=mode)
+    N.call('mmseg_conv2d_fwd_t', x, None, w, None, None, y, None, B, H, H, Cin, 0, H, H, Cout, 3, 3, 1, 1, 1, 0, 0, 1, 0.0, 0, 4)
+    assert torch.equal(y, y32.to(mode))
+    with pytest.raises(N.NativeLibraryError):      # a 16-bit INPUT needs the MFMA fast path
+        N.call('mmseg_conv2d_fwd_t', x.to(mode), None, w, None, None, y, None, B, H, H, Cin, 0, H, H, Cout, 3, 3, 1, 1, 1, 0, 0, 1, 0.0, 0, 5)
+
+
+def test_16bit_io_needs_a_reduced_precision_mode():
+    assert P.set_conv_precision('fp32') in ('fp32', 'bf16', 'fp16')
+    x = rnd(1, 16, 16, 64).to(DEV)
+    w = (rnd(3, 3, 64, 64) * 0.05).to(DEV)
+    wp = torch.empty(w.numel(), device=DEV)
+    N.call('mmseg_conv2d_wprep', w, wp, 3, 3, 64, 64, 0)
+    y = torch.empty(1, 16, 16, 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(N.NativeLibraryError):
+        N.call('mmseg_conv2d_fwd_t', x, None, w, wp, None, y, None, 1, 16, 16, 64, 0, 16, 16, 64, 3, 3, 1, 1, 1, 0, 0, 0, 0.0, 0, 4)
+
+
+@pytest.mark.parametrize('H,C1,C2,Cout,ups', [(32, 64, 0, 64, 0), (16, 128, 128, 128, 0), (32, 64, 0, 128, 0), (16, 128, 0, 64, 1)])
+def test_wgrad_16bit_operands(H, C1, C2, Cout, ups, mode):
+    B = 2
+    H1 = H // 2 if ups else H
+    x1 = rnd(B, H1, H1, C1, seed=11).to(mode).to(DEV)
+    x2 = rnd(B, H, H, C2, seed=12).to(mode).to(DEV) if C2 else None
+    dy = rnd(B, H, H, Cout, seed=13).to(mode).to(DEV)
+    Cin = C1 + C2
+    need = N.call('mmseg_conv2d_wgrad_workspace', B, H, H, Cin, Cout, 3, 3)
+    ws = torch.empty(max(need, 1), device=DEV)
+    ref = torch.zeros(3, 3, Cin, Cout, device=DEV)
+    N.call('mmseg_conv2d_wgrad', x1.float(), x2.float() if C2 else None, dy.float(), ref.view(-1), ws, ws.numel(), B, H, H, C1, C2, H, H, Cout,
+           3, 3, 1, 1, 1, ups, 0)
+    for io in (5, 1, 4):
+        got = torch.zeros_like(ref)
+        a1 = x1 if io & 1 else x1.float()
+        a2 = (x2 if io & 1 else x2.float()) if C2 else None
+        g = dy if io & 4 else dy.float()
+        N.call('mmseg_conv2d_wgrad_t', a1, a2, g, got.view(-1), ws, ws.numel(), B, H, H, C1, C2, H, H, Cout, 3, 3, 1, 1, 1, ups, 0, io)
+        assert torch.equal(got, ref), 'io=%d: max diff %g' % (io, float((got - ref).abs().max()))
+
+
+@pytest.mark.parametrize('hx,hy', [(0, 1), (1, 1), (1, 0)])
+def test_batchnorm_maxpool_upsample_typed_io(hx, hy, mode):
+    """the typed-I/O kernels against the fp32 kernels on representable inputs: statistics and the fp32 results bit-identical up to
+    the final rounding of 16-bit outputs"""
+    B, H, C = 2, 16, 128
+    M = B * H * H
+    tx = mode if hx else torch.float32
+    ty = mode if hy else torch.float32
+    x = (rnd(B, H, H, C, seed=21) * 1.5 + 0.3).to(mode).to(DEV)         # representable in the 16-bit type
+    gamma, beta = (rnd(C, seed=22) * 0.2 + 1).to(DEV), (rnd(C, seed=23) * 0.1).to(DEV)
+    hcode = lambda f: (1 if mode == torch.bfloat16 else 2) if f else 0
+    wsn = torch.empty(N.call('mmseg_norm_workspace_floats', C), device=DEV)
+    st_ref, st = torch.empty(4, C, device=DEV), torch.empty(4, C, device=DEV)
+    mm, mv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mm2, mv2 = mm.clone(), mv.clone()
+    xf = x.float()
+    N.call('mmseg_bn_stats', xf, gamma, beta, st_ref[0], st_ref[1], st_ref[2], st_ref[3], mm, mv, wsn, M, C, 1e-3, 0.99)
+    xin = x.to(tx)
+    N.call('mmseg_bn_stats_t', xin, gamma, beta, st[0], st[1], st[2], st[3], mm2, mv2, wsn, M, C, 1e-3, 0.99, hcode(hx))
+    assert torch.equal(st, st_ref) and torch.equal(mm, mm2) and torch.equal(mv, mv2)
+    y_ref = torch.empty_like(xf)
+    N.call('mmseg_bn_apply', xf, st[2], st[3], y_ref, M, C, 1)
+    y = torch.empty(B, H, H, C, device=DEV, dtype=ty)
+    N.call('mmseg_bn_apply_t', xin, st[2], st[3], y, M, C, 1, hcode(hx), hcode(hy))
+    assert torch.equal(y, y_ref.to(ty))
+    # backward on a representable upstream gradient and the (possibly rounded) y
+    dy = rnd(B, H, H, C, seed=24).to(mode).to(DEV)
+    yq = y.float()                                                       # what the backward pass sees as y
+    dx_ref, dg_ref, db_ref = torch.empty_like(xf), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    coef = torch.empty(3 * C, device=DEV)
+    N.call('mmseg_bn_bwd', dy.float(), yq, xf, gamma, st[0], st[1], dx_ref, dg_ref, db_ref, coef, wsn, M, C, 1, 1)
+    dx, dg, db = torch.empty(B, H, H, C, device=DEV, dtype=tx), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    N.call('mmseg_bn_bwd_t', dy.to(ty), y, xin, gamma, st[0], st[1], dx, dg, db, coef, wsn, M, C, 1, 1, hcode(hx), hcode(hy))
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    assert torch.equal(dx, dx_ref.to(tx))
+    if hx == hy and hx:
+        # pooling and the up-sampling gradient on 16-bit tensors
+        p_ref = torch.empty(B, H // 2, H // 2, C, device=DEV)
+        N.call('mmseg_maxpool2_fwd', xf, p_ref, B, H, H, C)
+        pq = torch.empty(B, H // 2, H // 2, C, device=DEV, dtype=mode)
+        N.call('mmseg_maxpool2_fwd_t', x, pq, B, H, H, C, hcode(1))
+        assert torch.equal(pq, p_ref.to(mode))
+        gp = rnd(B, H // 2, H // 2, C, seed=25).to(mode).to(DEV)
+        dxp_ref = torch.empty_like(xf)
+        N.call('mmseg_maxpool2_bwd', xf, p_ref, gp.float(), dxp_ref, B, H, H, C)
+        dxp = torch.empty_like(x)
+        N.call('mmseg_maxpool2_bwd_t', x, pq, gp, dxp, B, H, H, C, hcode(1))
+        assert torch.equal(dxp, dxp_ref.to(mode))
+        u_ref = torch.empty(B, H // 2, H // 2, C, device=DEV)
+        N.call('mmseg_upsample2_bwd', dy.float(), u_ref, B, H // 2, H // 2, C)
+        u = torch.empty(B, H // 2, H // 2, C, device=DEV, dtype=mode)
+        N.call('mmseg_upsample2_bwd_t', dy, u, B, H // 2, H // 2, C, hcode(1))
+        assert torch.equal(u, u_ref.to(mode))
