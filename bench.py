@@ -85,6 +85,11 @@ class ConvTimer(object):
         timer = self
 
         def call(name, *args):
+            full_name = name
+            io = 0
+            if name in ('mmseg_conv2d_fwd_t', 'mmseg_conv2d_fwd_scaled_t', 'mmseg_conv2d_wgrad_t'):
+                name, io = name[:-2], args[-1]       # same leading arguments + the 16-bit storage bits (x1, x2, y / dy)
+            e1, e2, e3 = (2.0 if io & 1 else 4.0), (2.0 if io & 2 else 4.0), (2.0 if io & 4 else 4.0)
             if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_fwd_scaled', 'mmseg_conv2d_wgrad',
                                           'mmseg_conv2d_dgrad_parity', 'mmseg_conv2d_dgrad_parity_all'):
                 if name == 'mmseg_conv2d_dgrad_parity_all':
@@ -105,7 +110,7 @@ class ConvTimer(object):
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[7:17]
                     ups = args[20]
                     flops = 2.0 * B * Ho * Wo * Cout * KH * KW * (C1 + C2)
-                    nbytes = 4.0 * (B * (H >> ups) * (W >> ups) * C1 + B * H * W * C2 + KH * KW * (C1 + C2) * Cout + B * Ho * Wo * Cout)
+                    nbytes = e1 * B * (H >> ups) * (W >> ups) * C1 + e2 * B * H * W * C2 + 4.0 * KH * KW * (C1 + C2) * Cout + e3 * B * Ho * Wo * Cout
                     kind = 'conv_fwd_kernel'
                     shape = ('fwd+bn', B, H, W, C1, C2, Cout, KH, KW, 'ups' if ups else '')
                 elif name == 'mmseg_conv2d_fwd':
@@ -117,14 +122,14 @@ class ConvTimer(object):
                     flops = 2.0 * pix * Cout * KH * KW * (C1 + C2)
                     ups = args[20]
                     # algorithmic bytes: every input element, weight and output element once
-                    nbytes = 4.0 * (B * (H >> ups) * (W >> ups) * C1 + B * H * W * C2 + KH * KW * (C1 + C2) * Cout + B * Ho * Wo * Cout)
+                    nbytes = e1 * B * (H >> ups) * (W >> ups) * C1 + e2 * B * H * W * C2 + 4.0 * KH * KW * (C1 + C2) * Cout + e3 * B * Ho * Wo * Cout
                     kind = 'conv_fwd_kernel'
                     shape = ('dgrad_T' if transposed else 'fwd', B, H, W, C1, C2, Cout, KH, KW, 'ups' if ups else '')
                 else:
                     (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW) = args[6:16]
                     flops = 2.0 * B * Ho * Wo * Cout * KH * KW * (C1 + C2)
                     ups = args[19]
-                    nbytes = 4.0 * (B * (H >> ups) * (W >> ups) * C1 + B * H * W * C2 + KH * KW * (C1 + C2) * Cout + B * Ho * Wo * Cout)
+                    nbytes = e1 * B * (H >> ups) * (W >> ups) * C1 + e2 * B * H * W * C2 + 4.0 * KH * KW * (C1 + C2) * Cout + e3 * B * Ho * Wo * Cout
                     kind = 'conv_wgrad_kernel'
                     shape = ('wgrad', B, H, W, C1, C2, Cout, KH, KW, 'ups' if ups else '')
                 timer.counts[kind] = timer.counts.get(kind, 0) + 1
@@ -133,14 +138,14 @@ class ConvTimer(object):
                 if sampled:
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
-                rc = timer._orig(name, *args)
+                rc = timer._orig(full_name, *args)
                 kname = kernel_name(timer._orig('mmseg_conv2d_last_kernel'), timer.prec)     # which template instance ran
                 timer.kcounts[kname] = timer.kcounts.get(kname, 0) + 1
                 if sampled:
                     e.record()
                     timer.records.append((kind, flops, nbytes, s, e, shape, kname))
                 return rc
-            return timer._orig(name, *args)
+            return timer._orig(full_name, *args)
         _native.call = call
 
     def breakdown(self, steps):
@@ -256,6 +261,8 @@ def main():
     ap.add_argument('--l_mix', type=float, default=1.0)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f16'],
                     help='bf16: bf16 MFMA operands (fp32 accumulation, fp32 tensors in HBM, fp32 weight gradients) -- configs #3/#5')
+    ap.add_argument('--act16', action='store_true',
+                    help='with --dtype bf16 | f16: the activations / gradients of the MFMA trunk live in HBM in the 16-bit type (conf.act_storage = half)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
     ap.add_argument('--conv-breakdown', action='store_true', help='per-shape convolution table on stderr')
@@ -309,6 +316,11 @@ def main():
     cfg['l_mix'] = args.l_mix
     cfg['n_pairs'] = 1
     cfg['compute_dtype'] = {'f32': 'fp32', 'bf16': 'bf16', 'f16': 'fp16'}[args.dtype]
+    if args.act16:
+        if args.dtype == 'f32':
+            raise SystemExit('--act16 needs --dtype bf16 or f16')
+        cfg['act_storage'] = 'half'
+        DTYPE_NAME[args.dtype] = DTYPE_NAME[args.dtype].replace('(fp32 accumulate)', '(fp32 accumulate), 16-bit trunk activations in HBM')
     cfg['folder'] = '/tmp/mmseg_bench'
     conf = EasyDict(cfg)
 
@@ -397,13 +409,14 @@ def main():
         summ = timer.summary() if not args.no_conv_timer else {}
         # HBM bytes per launch from rocprofv3 PMC passes of THIS workload (tools/pmc_traffic.py), keyed by workload and kernel
         wkey = '%s-%s-%d-bs%d-%s-lmix%g' % (args.model if args.model != 'mmsdnet' or args.modalities == 2 else 'mmsdnet3',
-                                          args.decoder, H, args.batch, args.dtype, args.l_mix)
+                                          args.decoder, H, args.batch, args.dtype + ('-act16' if args.act16 else ''), args.l_mix)
         traffic = {}
         tpath = os.path.join(ROOT, 'profiles', 'r02_conv_traffic.json')
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get('workloads', {}).get(wkey, {})
         peak = BF16_MFMA_PEAK_TFLOPS if args.dtype in ('bf16', 'f16') else FP32_MFMA_PEAK_TFLOPS
-        prec_note = '%s MFMA operands (fp32 tensors in HBM, fp32 accumulation)' % args.dtype if args.dtype != 'f32' else 'fp32 MFMA'
+        prec_note = '%s MFMA operands (%s, fp32 accumulation)' % (args.dtype, '16-bit trunk activations + fp32 elsewhere in HBM' if args.act16
+                                                                     else 'fp32 tensors in HBM') if args.dtype != 'f32' else 'fp32 MFMA'
 
         def entry(k, launches, label):
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12

@@ -98,6 +98,7 @@ int mmseg_conv2d_dgrad_tapsum(const float* T, float* dx, int B, int H, int W, in
 long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 /* mmseg_conv2d_wgrad with 16-bit operands in HBM (reduced-precision modes; stride 1 and Wo % 4 == 0 only): io bit 0 = x1 (and x2),
  * bit 2 = dy hold 16-bit elements; dw and the workspace stay fp32 */
+int mmseg_conv2d_wgrad_t_supported(int Ho, int Wo, int stride, int C1, int C2, int Cout);
 int mmseg_conv2d_wgrad_t(const void* x1, const void* x2, const void* dy, float* dw, float* ws, long ws_floats,
                          int B, int H, int W, int C1, int C2, int Ho, int Wo, int Cout, int KH, int KW, int stride,
                          int pad_h, int pad_w, int ups, int accumulate, int io, void* stream);

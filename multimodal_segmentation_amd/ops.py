@@ -235,10 +235,16 @@ class _Conv2d(torch.autograd.Function):
             need = N.call('mmseg_conv2d_wgrad_workspace', B, Ho, Wo, C1 + C2, Cout, KH, KW)
             ws = _ws('wgrad', need, dy.device)
             # accumulates straight into the gradient-arena view (the final slab reduction adds to it)
-            if _h(x1) or _h(x2) or _h(g):       # 16-bit operands in HBM: the transposed-staging kernel reads them as they are
+            if (_h(x1) or _h(x2) or _h(g)) and N.call('mmseg_conv2d_wgrad_t_supported', Ho, Wo, stride, C1, C2, Cout):
+                # 16-bit operands in HBM: the transposed-staging kernel reads them as they are
                 assert x2 is None or _h(x2) == _h(x1)
                 N.call('mmseg_conv2d_wgrad_t', x1, x2, g, ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
                        stride, ph, pw, ups, 1, (1 if _h(x1) else 0) | (4 if _h(g) else 0))
+            elif _h(x1) or _h(x2) or _h(g):
+                # geometry the 16-bit kernel does not take (tiny planes): widen the operands (a copy, no arithmetic)
+                f = lambda t: t if t is None or _h(t) == 0 else t.float()
+                N.call('mmseg_conv2d_wgrad', f(x1), f(x2), f(g), ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
+                       stride, ph, pw, ups, 1)
             else:
                 N.call('mmseg_conv2d_wgrad', x1, x2, g, ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
                        stride, ph, pw, ups, 1)

@@ -152,3 +152,50 @@ def test_batchnorm_maxpool_upsample_typed_io(hx, hy, mode):
         u = torch.empty(B, H // 2, H // 2, C, device=DEV, dtype=mode)
         N.call('mmseg_upsample2_bwd_t', dy, u, B, H // 2, H // 2, C, hcode(1))
         assert torch.equal(u, u_ref.to(mode))
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'fp16'])
+def test_generator_step_with_16bit_trunk_storage_close_to_fp32_storage(dt):
+    """conf.act_storage = 'half' at the model level: a teacher-forced DAFNet generator step with the trunk's activations and gradients
+    stored in 16 bits against the same step with fp32 storage (same 16-bit MFMA compute mode, same weights and draws): every loss
+    term within 3e-2 relative (the only difference is the rounding of the stored tensors), and the 16-bit tensors really exist."""
+    from multimodal_segmentation_amd import nn
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    B, H = 2, 64
+    d = Hh.make_step_data(B, H, H)
+    B1 = np.ones((B, 1), np.float32)
+    tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [B1] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [B1] * 4 + \
+         [np.zeros(B, np.float32)] * 2 + [d['z1'], d['z2']]
+    res, teacher, ref_w = {}, None, None
+    try:
+        for storage in ('fp32', 'half'):
+            conf = Hh.make_conf(dafnet_config_chaos, H, compute_dtype=dt, act_storage=storage)
+            model = DAFNet(conf)
+            model.build()
+            assert (P.act16_dtype() is not None) == (storage == 'half')
+            ms = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
+            if ref_w is None:
+                ref_w = [m.get_weights() for m in ms]
+            else:
+                for m, w in zip(ms, ref_w):
+                    m.set_weights(w)
+            h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']], teacher_s=teacher)
+            if teacher is None:
+                teacher = [model.last_factors['s1'].detach().clone(), model.last_factors['s2'].detach().clone()]
+            res[storage] = {k: h.history[k][0] for k in h.history.keys()}
+            if storage == 'half':
+                # the segmentor's first block hands a 16-bit tensor to its second convolution
+                x = torch.zeros(B, H, H, 8, device='cuda')
+                with torch.no_grad():
+                    l = nn.conv_bn(model.Segmentor, 'c0', 'c0_bn', x, False, relu=True)
+                assert l.dtype == P.act16_dtype()
+    finally:
+        P.set_activation_storage(False)
+        P.set_conv_precision('fp32')
+    for k, v in res['fp32'].items():
+        tol = 6e-2 if k in ('loss', 'D_Mask_loss', 'D_Image1_loss', 'D_Image2_loss') else 3e-2
+        assert np.isfinite(res['half'][k]) and abs(res['half'][k] - v) <= tol * max(1.0, abs(v)), (k, v, res['half'][k])
+    assert any(abs(res['half'][k] - v) > 1e-7 for k, v in res['fp32'].items())

@@ -32,6 +32,12 @@ def main():
     check = os.environ.get('CHECK', '0') == '1'
     dev = torch.device('cuda')
     N.load()
+    # DTYPE=bf16|fp16 selects the reduced-precision mode; IO=<bits> stores x (1 | 2) and / or y (4) as 16-bit tensors (mmseg_conv2d_fwd_t)
+    dt = os.environ.get('DTYPE', 'fp32')
+    io = int(os.environ.get('IO', '0'))
+    from multimodal_segmentation_amd import ops as P
+    P.set_conv_precision(dt)
+    half = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(dt)
     for name, H, C1, C2, Cout, ups in SHAPES:
         g = torch.Generator().manual_seed(2)
         H1 = H // 2 if ups else H
@@ -44,6 +50,12 @@ def main():
         wp = torch.empty(w.numel(), device=dev)
         N.call('mmseg_conv2d_wprep', w, wp, 3, 3, Cin, Cout, 0)
         run = lambda: N.call('mmseg_conv2d_fwd', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, 3, 3, 1, 1, 1, ups, 0, 1, 0.0, 0)
+        if io:
+            xa = x1.to(half) if io & 1 else x1
+            xb = (x2.to(half) if io & 1 else x2) if C2 else None
+            ya = torch.empty(B, H, H, Cout, device=dev, dtype=half if io & 4 else torch.float32)
+            run = lambda: N.call('mmseg_conv2d_fwd_t', xa, xb, w, wp, b, ya, None, B, H, H, C1, C2, H, H, Cout, 3, 3, 1, 1, 1, ups, 0, 1, 0.0, 0,
+                                 (1 if io & 1 else 0) | (2 if (io & 1 and C2) else 0) | (io & 4))
         t = timeit(run)
         flops = 2.0 * B * H * H * Cin * Cout * 9
         err = ''

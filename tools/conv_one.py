@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Run one convolution shape a few times (for rocprofv3 --pmc): python tools/conv_one.py H Cin Cout [fwd|wgrad]"""
+"""Run one convolution shape a few times (for rocprofv3 --pmc): [DTYPE=bf16|fp16 [IO=<bits>]] python tools/conv_one.py H Cin Cout [fwd|wgrad]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,8 +13,16 @@ x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(k, k, Cin, Cout, devi
 y = torch.empty(B, H, H, Cout, device=dev); wp = torch.empty(w.numel(), device=dev); dw = torch.empty_like(w)
 N.call('mmseg_conv2d_wprep', w, wp, k, k, Cin, Cout, 0)
 need = N.call('mmseg_conv2d_wgrad_workspace', B, H, H, Cin, Cout, k, k); ws = torch.empty(max(need, 1), device=dev)
+dt, io = os.environ.get('DTYPE', 'fp32'), int(os.environ.get('IO', '0'))
+from multimodal_segmentation_amd import ops as P
+P.set_conv_precision(dt)
+half = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(dt)
+xa = x.to(half) if io & 1 else x
+ya = y.to(half) if io & 4 else y
 for _ in range(5):
-    if mode == 'fwd':
+    if mode == 'fwd' and io:
+        N.call('mmseg_conv2d_fwd_t', xa, None, w, wp, None, ya, None, B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0, 0, 0, 0.0, 0, io & 5)
+    elif mode == 'fwd':
         N.call('mmseg_conv2d_fwd', x, None, w, wp, None, y, None, B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0, 0, 0, 0.0, 0)
     else:
         N.call('mmseg_conv2d_wgrad', x, None, y, dw, ws, ws.numel(), B, H, H, Cin, 0, H, H, Cout, k, k, 1, p, p, 0, 0)

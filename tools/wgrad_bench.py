@@ -5,6 +5,7 @@ time, TFLOP/s and -- with CHECK=1 -- the deviation from torch's own convolution 
     python tools/wgrad_bench.py                 # table
     MMSEG_WGRAD_TR=0 python tools/wgrad_bench.py   # the round-1 kernel (pixel-major LDS tiles, many slabs)
     MMSEG_WGRAD_TR_S=<n> ...                    # force the number of slabs of the transposed-staging kernel
+    DTYPE=bf16|fp16 [IO=<bits>] ...             # reduced-precision products; IO: x (1|2) and / or dy (4) stored 16-bit (mmseg_conv2d_wgrad_t)
 """
 import os
 import sys
@@ -43,6 +44,11 @@ def main():
     only = os.environ.get('ONLY')
     dev = torch.device('cuda')
     N.load()
+    dt = os.environ.get('DTYPE', 'fp32')
+    io = int(os.environ.get('IO', '0'))
+    from multimodal_segmentation_amd import ops as P
+    P.set_conv_precision(dt)
+    half = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(dt)
     tot_t = tot_f = 0.0
     print('%-18s %6s %10s %9s %9s %s' % ('layer', 'H', 'C1+C2->N', 'ms', 'TFLOP/s', 'max rel err' if check else ''))
     for name, H, C1, C2, Cout, ups in SHAPES:
@@ -59,6 +65,13 @@ def main():
         ws = torch.empty(max(need, 1), device=dev)
         run = lambda acc=0: N.call('mmseg_conv2d_wgrad', x1, x2, dy, dw.view(-1), ws, ws.numel(), B, H, H, C1, C2, H, H, Cout, 3, 3,
                                    1, 1, 1, ups, acc)
+        if io and N.call('mmseg_conv2d_wgrad_t_supported', H, H, 1, C1, C2, Cout):
+            xa = x1.to(half) if io & 1 else x1
+            xb = (x2.to(half) if io & 1 else x2) if C2 else None
+            da = dy.to(half) if io & 4 else dy
+            bits = (1 if io & 1 else 0) | (2 if (io & 1 and C2) else 0) | (io & 4)
+            run = lambda acc=0: N.call('mmseg_conv2d_wgrad_t', xa, xb, da, dw.view(-1), ws, ws.numel(), B, H, H, C1, C2, H, H, Cout, 3, 3,
+                                       1, 1, 1, ups, acc, bits)
         t = timeit(run)
         flops = 2.0 * B * H * H * Cin * Cout * 9
         err = ''
