@@ -47,10 +47,13 @@ def kernel_name(kid, prec):
     """mmseg_conv2d_last_kernel() id -> the kernel name rocprofv3 reports (template arguments included)"""
     fam, rest = kid // 1000000, kid % 1000000
     flag, rest = rest // 500000, rest % 500000
+    k64, rest = rest // 250000, rest % 250000
     bm, bn = rest // 1000, rest % 1000
     wm, wn = (4, 1) if bn == 32 else (2, 2)
     tf = 'true' if flag else 'false'
-    if fam in (1, 4, 7):
+    if fam in (1, 4):          # <M tile, N tile, waves M, waves N, precision, 16-bit input, K tile>
+        return '%s<%d, %d, %d, %d, %d, %s, %d>' % (_FAMILY[fam], bm, bn, wm, wn, prec, tf, 64 if k64 else 32)
+    if fam == 7:
         return '%s<%d, %d, %d, %d, %d>' % (_FAMILY[fam], bm, bn, wm, wn, prec)
     if fam in (2, 8):
         return '%s<%d, %d, %d, %d, %s>' % (_FAMILY[fam], bm, bn, wm, wn, tf)

@@ -69,9 +69,12 @@ int mmseg_conv2d_fwd_scaled_t(const void* x1, const void* x2, const float* w, co
  * 1 conv_fast_kernel, 2 conv_fwd_kernel, 3 conv_direct_kernel, 4 conv_fast_batched_kernel, 5 conv_dgrad_s2k4_smallc_kernel,
  * 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel (profiling aid, no launch) */
 int mmseg_conv2d_last_kernel(void);
-/* fast path (Cin % 32 == 0, not transposed): K tiles lie inside one tap, gather by buffer loads, weights read from
+/* fast path (Cin % 32 == 0, not transposed, at most 32 taps -- the reference's largest kernel is 5 x 5; more taps fall back to the
+ * generic kernel, which reads `w`): K tiles lie inside one tap, gather by buffer loads, weights read from
  * `wt` = the kernel re-laid out as [Cout][K] by mmseg_conv2d_wprep (mode 0 forward, mode 1 data gradient incl. the
- * spatial flip); pass wt = NULL to force the generic kernel. */
+ * spatial flip, mode 2 the kernel as it is, in the image's element type); pass wt = NULL to force the generic kernel.  In the reduced-precision modes (mmseg_set_conv_precision 1 | 2) the
+ * image holds elements of the 16-bit MFMA operand type (rounded once by the prep launch; it occupies the first half of the same
+ * fp32-sized buffer) -- prepare it in the mode the convolution runs in. */
 int mmseg_conv2d_fast_path(int C1, int C2, int Cout, int transposed);
 int mmseg_conv2d_wprep(const float* w, float* out, int KH, int KW, int Cin, int Cout, int mode, void* stream);
 /* data gradient of a STRIDED convolution, one launch per parity class (ph, pw) of the input pixels: only the taps

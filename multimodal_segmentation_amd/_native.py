@@ -13,7 +13,8 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_PKG_DIR, 'csrc')
-LIB_PATH = os.path.join(CSRC_DIR, 'libmmseg_hip.so')
+# MMSEG_HIP_LIB: another build of the same library (A/B measurements of kernel variants); the default is the in-tree build
+LIB_PATH = os.environ.get('MMSEG_HIP_LIB') or os.path.join(CSRC_DIR, 'libmmseg_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'mmseg_hip.h')
 SOURCES = ('conv.hip', 'pointwise.hip', 'norm.hip', 'act16.hip', 'dense.hip', 'tps.hip', 'augment.hip', 'loss.hip', 'pairloss.hip', 'optim.hip')
 

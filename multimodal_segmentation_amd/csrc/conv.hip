@@ -307,25 +307,32 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
-template <int BM, int BN, int WM, int WN, int PREC = 0>
+template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false, int KT = BK>
 __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bid, const int nblk) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_RPP = NT / 8, A_F4 = BM / A_RPP;
-    constexpr int B_F4 = (BN + A_RPP - 1) / A_RPP;       // weight rows (output channels) are staged exactly like pixel rows
+    static_assert(KT == 32 || (KT == 64 && PREC != 0), "K tile: 32 channels, or 64 in the 16-bit modes");
     // LDS tiles: 32 floats per row, NO padding; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7, which makes
     // both the ds_write_b128 (8 lanes = 8 chunks of one row) and the ds_read_b128 (16-lane groups over distinct rows)
     // conflict-free and lets 3 blocks of the 128x64 tile share a CU's 160 KB
     // BF16 variant (mmseg_set_conv_precision(1)): the fp32 operands are rounded to bf16 (RNE) on their way into LDS, the tiles
-    // are rows of 32 bf16 = 64 bytes (4 chunks of 16 bytes, chunk index XOR-swizzled with (row >> 1) & 3: conflict-free for
-    // the 8-byte stores and the 16-byte operand reads alike), products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+    // are rows of 32 bf16 = 64 bytes (4 chunks of 16 bytes, chunk index XOR-swizzled with (row >> 2) & 3: conflict-free for
+    // the stores and -- over ds_read_b128's lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} -- the 16-byte operand reads
+    // alike; (row >> 1) & 3 left the reads 2-way conflicted), products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+    // KT = 64 (16-bit modes, layers whose channel counts are multiples of 64): rows of 64 elements = 128 bytes, i.e. byte for
+    // byte the fp32 tile's geometry and swizzle; a stage then carries twice the MFMAs per barrier, load wait and LDS round trip
+    // -- the 16-bit MFMAs finish a 32-deep stage in a quarter of the fp32 time and were waiting on exactly those.
     // LD counts 4-byte words per row.
     constexpr bool BF16 = PREC != 0;         // any 16-bit operand mode (bf16 or fp16): same tile geometry
     typedef typename LowPrec<PREC>::T LT;
     typedef typename LowPrec<PREC>::V4 LV4;
     typedef typename LowPrec<PREC>::V8 LV8;
-    constexpr int LD = BF16 ? BK / 2 : BK;
+    constexpr int LD = BF16 ? KT / 2 : KT;                // words per LDS row (16 or 32)
+    constexpr int NCH = LD / 4;                           // 16-byte chunks per LDS row (4 or 8)
     constexpr int A_SZ = BM * LD, B_SZ = BN * LD;
+    // staging geometry: a lane moves 16 bytes of SOURCE; LPA / LPB lanes cover one row of the activation / weight tile
+    constexpr int LPA = KT * (IN16 ? 2 : 4) / 16, LPB = KT * (BF16 ? 2 : 4) / 16;
+    constexpr int A_RPP = NT / 8;                         // (rows per pass of the 8-lanes-per-row mapping; kept for the weight tile of the fp32 kernel)
 
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
     float* As = smem;
@@ -356,129 +363,132 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
         return tile2d ? (t_b * p.Ho + t_y0 + (row >> 4)) * p.Wo + t_x0 + (row & 15) : m0 + row;
     };
 
-    // 16-bit input tensors (reduced-precision modes, ConvParams::io; x1 and x2 together): elements are 2 bytes and a lane's 16-byte
-    // load covers 8 channels, so 4 lanes (not 8) stage a 32-channel row and a pass of the block covers 64 rows (not 32) -- half the
-    // load and LDS-store instructions of the fp32-input tile
-    const bool in16 = BF16 && (p.io & 1);
-    const int es1 = in16 ? 2 : 4, es2 = es1;
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * es1, 0x00020000);
+    // 16-bit input tensors (reduced-precision modes, ConvParams::io bit 0 -> IN16; x1 and x2 together): elements are 2 bytes and a
+    // lane's 16-byte load covers 8 channels, so 4 lanes (not 8) stage a 32-channel row and a pass of the block covers 64 rows (not
+    // 32) -- half the load and LDS-store instructions of the fp32-input tile
+    constexpr int ES = IN16 ? 2 : 4;                       // bytes per input element
+    constexpr int A_RPA = NT / LPA;                        // rows per staging pass of the activation tile ...
+    constexpr int A_NP = (BM + A_RPA - 1) / A_RPA;         // ... and passes
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * ES, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
-                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * es2 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.K * p.Cout * 4, 0x00020000);
+                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * ES : 0, 0x00020000);
+    // the weight image holds MFMA-operand-type elements in the reduced-precision modes (mmseg_conv2d_wprep rounds once)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.K * p.Cout * (BF16 ? 2 : 4), 0x00020000);
 
     // ---- per-thread row state: element offsets of (b, hb, wb, first channel of the lane's chunk) in x1 / x2 ----------------
-    const int kc = tid & 7, ar0 = tid >> 3;            // weight-tile staging (always fp32): 8 lanes per row
-    const int kcA = in16 ? (tid & 3) : kc;             // activation-tile staging: chunk of the lane ...
-    const int arA = in16 ? (tid >> 2) : ar0;           // ... its first row ...
-    const int rppA = in16 ? 2 * A_RPP : A_RPP;         // ... rows per pass ...
-    const int npA = in16 ? (A_F4 + 1) / 2 : A_F4;      // ... passes ...
-    const int ecA = (in16 ? 8 : 4) * kcA;              // ... and first channel of its chunk inside the 32-channel K tile
-    int a_hb[A_F4], a_wb[A_F4], a_o1[A_F4], a_o2[A_F4];
+    const int kcA = tid % LPA;                         // activation-tile staging: 16-byte source piece of the lane ...
+    const int arA = tid / LPA;                         // ... its first row ...
+    const int ecA = (IN16 ? 8 : 4) * kcA;              // ... and first channel of its piece inside the K tile
+    // a_msk: bit (kh * KW + kw) = that tap of the row lies inside the image (the host keeps KH * KW <= 32 on this path), so the
+    // inner loop tests one bit instead of re-deriving (hi, wi) and comparing; a_o1 / a_o2 are BYTE offsets (x1 without up-sampling, x2)
+    int a_hb[A_NP], a_wb[A_NP], a_o1[A_NP], a_o2[A_NP];
+    unsigned a_msk[A_NP];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
-    for (int j = 0; j < A_F4; ++j) {
-        const int row = arA + j * rppA;
-        const int m = (j < npA && row < BM) ? row_to_m(row) : p.M;
+    for (int j = 0; j < A_NP; ++j) {
+        const int row = arA + j * A_RPA;
+        const int m = (BM % A_RPA == 0 || row < BM) ? row_to_m(row) : p.M;
+        a_msk[j] = 0u;
         if (m < p.M) {
             const int b = m / HoWo, r = m - b * HoWo;
             const int ho = r / p.Wo, wo = r - ho * p.Wo;
             const int hb = ho * p.stride - p.pad_h, wb = wo * p.stride - p.pad_w;
             a_hb[j] = hb; a_wb[j] = wb;
-            a_o1[j] = p.ups ? b * p.H1 : ((b * p.H + hb) * p.W + wb) * p.C1 + ecA;
-            a_o2[j] = ((b * p.H + hb) * p.W + wb) * p.C2 + ecA;
+            a_o1[j] = p.ups ? b * p.H1 : (((b * p.H + hb) * p.W + wb) * p.C1 + ecA) * ES;
+            a_o2[j] = (((b * p.H + hb) * p.W + wb) * p.C2 + ecA) * ES;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw)
+                    if ((unsigned)(hb + kh) < (unsigned)p.H && (unsigned)(wb + kw) < (unsigned)p.W) a_msk[j] |= 1u << (kh * p.KW + kw);
         } else {
-            a_hb[j] = -(1 << 28); a_wb[j] = -(1 << 28); a_o1[j] = 0; a_o2[j] = 0;
+            a_hb[j] = 0; a_wb[j] = 0; a_o1[j] = 0; a_o2[j] = 0;
         }
     }
     const int Cin = p.C1 + p.C2;
     const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
     int s_c0 = 0, s_kh = 0, s_kw = 0;          // wave-uniform position of the next K tile: channel base, tap
-    int b_o[B_F4];                             // element offset of (n, 4*kc) in wt, or -1 for rows beyond Cout / BN
+    // weight tile: fp32 image = 4 floats per lane; 16-bit image = 8 elements per lane
+    constexpr int B_RPP = NT / LPB, B_NP = (BN + B_RPP - 1) / B_RPP;
+    const int kcB = tid % LPB, arB = tid / LPB;
+    constexpr int EB = BF16 ? 2 : 4;           // bytes per element of the weight image
+    constexpr int FAR = 0x40000000;            // added to a byte offset it puts the load out of range (the images stay below 2^30 bytes)
+    int b_o[B_NP];                             // byte offset of (n, first k of the lane's chunk) in wt, or FAR for rows beyond Cout / BN
 #pragma unroll
-    for (int j = 0; j < B_F4; ++j) {
-        const int row = ar0 + j * A_RPP, n = n0 + row;
-        b_o[j] = (row < BN && n < p.Cout) ? n * p.K + 4 * kc : -1;
+    for (int j = 0; j < B_NP; ++j) {
+        const int row = arB + j * B_RPP, n = n0 + row;
+        b_o[j] = ((BN % B_RPP == 0 || row < BN) && n < p.Cout) ? (n * p.K + (BF16 ? 8 : 4) * kcB) * EB : FAR;
     }
 
-    u32x4 ra[A_F4];         // the A tile in flight as raw bits: 4 floats, or (in16) 8 16-bit elements per lane
-    f32x4 rb[B_F4];
-    // 16 bytes at element offset `off` of a tensor with `es`-byte elements (4 floats or 8 16-bit elements); out of range -> zeros
-    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int off, bool ok, int es) -> u32x4 {
-        return __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off * es : BUF_OOB, 0, 0);
+    // a tile in flight as raw bits: 4 floats, or 8 16-bit elements per lane
+    struct Stage { u32x4 a[A_NP]; u32x4 b[B_NP]; };
+    // 16 bytes at byte offset `off` (4 floats or 8 16-bit elements); out of range -> zeros
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int off, bool ok) -> u32x4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : BUF_OOB, 0, 0);
     };
-    auto load_tile = [&]() {
+    // `live` = the tile exists (the two-tile prefetch of the 16-bit kernels issues its loads unconditionally, so that the
+    // outstanding-load count the compiler waits on is exact; loads of a tile beyond K get out-of-range offsets = no traffic)
+    auto load_tile = [&](Stage& t, const bool live) {
         const int kh = s_kh, kw = s_kw;
-        const int b_koff = (kh * p.KW + kw) * Cin + s_c0;                  // first K column of the tile
+        const int tap = kh * p.KW + kw;
+        const unsigned tbit = live ? 1u << tap : 0u;                       // this tap's bit of the rows' validity masks
+        const int b_koff = live ? (tap * Cin + s_c0) * EB : FAR;           // first K column of the tile, in bytes
         if (s_c0 < p.C1) {
             if (p.ups) {
 #pragma unroll
-                for (int j = 0; j < A_F4; ++j) {
-                    if (j >= npA) break;
+                for (int j = 0; j < A_NP; ++j) {
                     const int hi = a_hb[j] + kh, wi = a_wb[j] + kw;
-                    const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                     const int off = ((a_o1[j] + (hi >> 1)) * p.W1 + (wi >> 1)) * p.C1 + s_c0 + ecA;
-                    ra[j] = ld4(r1, off, ok, es1);
+                    t.a[j] = ld4(r1, off * ES, (a_msk[j] & tbit) != 0u);
                 }
             } else {
-                const int toff = (kh * p.W + kw) * p.C1 + s_c0;
+                const int toff = ((kh * p.W + kw) * p.C1 + s_c0) * ES;
 #pragma unroll
-                for (int j = 0; j < A_F4; ++j) {
-                    if (j >= npA) break;
-                    const int hi = a_hb[j] + kh, wi = a_wb[j] + kw;
-                    const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                    ra[j] = ld4(r1, a_o1[j] + toff, ok, es1);
-                }
+                for (int j = 0; j < A_NP; ++j) t.a[j] = ld4(r1, a_o1[j] + toff, (a_msk[j] & tbit) != 0u);
             }
         } else {
-            const int toff = (kh * p.W + kw) * p.C2 + (s_c0 - p.C1);
+            const int toff = ((kh * p.W + kw) * p.C2 + (s_c0 - p.C1)) * ES;
 #pragma unroll
-            for (int j = 0; j < A_F4; ++j) {
-                if (j >= npA) break;
-                const int hi = a_hb[j] + kh, wi = a_wb[j] + kw;
-                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                ra[j] = ld4(r2, a_o2[j] + toff, ok, es2);
-            }
+            for (int j = 0; j < A_NP; ++j) t.a[j] = ld4(r2, a_o2[j] + toff, (a_msk[j] & tbit) != 0u);
         }
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) rb[j] = buf_load4(rw, b_o[j] >= 0 ? (b_o[j] + b_koff) * 4 : BUF_OOB);
+        for (int j = 0; j < B_NP; ++j) t.b[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_o[j] + b_koff, 0, 0);
         // advance the uniform K position by one tile: taps fastest inside a 32-channel chunk, so that consecutive
         // tiles re-read (shifted) the same cache lines
-        if (++s_kw == p.KW) { s_kw = 0; if (++s_kh == p.KH) { s_kh = 0; s_c0 += BK; } }
+        if (++s_kw == p.KW) { s_kw = 0; if (++s_kh == p.KH) { s_kh = 0; s_c0 += KT; } }
     };
-    auto store_tile = [&](int buf) {
+    // chunk swizzle of an LDS row: 8-chunk rows (128 bytes) (row >> 1) & 7, 4-chunk rows (64 bytes) (row >> 2) & 3
+    auto swz = [&](int row) -> int { return NCH == 8 ? (row >> 1) & 7 : (row >> 2) & 3; };
+    auto store_tile = [&](int buf, const Stage& t) {
         float* A = As + buf * A_SZ;
         float* Bt = Bs + buf * B_SZ;
         if constexpr (BF16) {
-            // fp32 input: this thread's 4 consecutive k = half of the 16-byte chunk kc >> 1
-            if (in16) {                          // already the MFMA operand type: the lane's 16 bytes are one chunk of its row
+            if constexpr (IN16) {                // already the MFMA operand type: the lane's 16 bytes are one chunk of its row
 #pragma unroll
-                for (int j = 0; j < A_F4; ++j) {
-                    const int row = arA + j * rppA;
-                    if (j < npA && row < BM) *reinterpret_cast<u32x4*>(&A[row * LD + 4 * (kcA ^ ((row >> 1) & 3))]) = ra[j];
+                for (int j = 0; j < A_NP; ++j) {
+                    const int row = arA + j * A_RPA;
+                    if (BM % A_RPA == 0 || row < BM) *reinterpret_cast<u32x4*>(&A[row * LD + 4 * (kcA ^ swz(row))]) = t.a[j];
                 }
-            } else {
+            } else {                             // fp32 input: this thread's 4 consecutive k = half of the 16-byte chunk kcA >> 1
 #pragma unroll
-                for (int j = 0; j < A_F4; ++j) {
-                    const int row = ar0 + j * A_RPP;
-                    const f32x4 f = __builtin_bit_cast(f32x4, ra[j]);
+                for (int j = 0; j < A_NP; ++j) {
+                    const int row = arA + j * A_RPA;
+                    const f32x4 f = __builtin_bit_cast(f32x4, t.a[j]);
                     LV4 v = {(LT)f[0], (LT)f[1], (LT)f[2], (LT)f[3]};
-                    *reinterpret_cast<LV4*>(&A[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)]) = v;
+                    if (BM % A_RPA == 0 || row < BM) *reinterpret_cast<LV4*>(&A[row * LD + 4 * ((kcA >> 1) ^ swz(row)) + 2 * (kcA & 1)]) = v;
                 }
             }
 #pragma unroll
-            for (int j = 0; j < B_F4; ++j) {
-                const int row = ar0 + j * A_RPP;
-                LV4 v = {(LT)rb[j][0], (LT)rb[j][1], (LT)rb[j][2], (LT)rb[j][3]};
-                if (row < BN) *reinterpret_cast<LV4*>(&Bt[row * LD + 4 * ((kc >> 1) ^ ((row >> 1) & 3)) + 2 * (kc & 1)]) = v;
+            for (int j = 0; j < B_NP; ++j) {
+                const int row = arB + j * B_RPP;
+                if (BN % B_RPP == 0 || row < BN) *reinterpret_cast<u32x4*>(&Bt[row * LD + 4 * (kcB ^ swz(row))]) = t.b[j];
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < A_F4; ++j)
-                *reinterpret_cast<u32x4*>(&A[(ar0 + j * A_RPP) * LD + 4 * (kc ^ (((ar0 + j * A_RPP) >> 1) & 7))]) = ra[j];
+            for (int j = 0; j < A_NP; ++j)
+                *reinterpret_cast<u32x4*>(&A[(arA + j * A_RPA) * LD + 4 * (kcA ^ swz(arA + j * A_RPA))]) = t.a[j];
 #pragma unroll
-            for (int j = 0; j < B_F4; ++j) {
-                const int row = ar0 + j * A_RPP;
-                if (row < BN) *reinterpret_cast<f32x4*>(&Bt[row * LD + 4 * (kc ^ ((row >> 1) & 7))]) = rb[j];
+            for (int j = 0; j < B_NP; ++j) {
+                const int row = arB + j * B_RPP;
+                if (BN % B_RPP == 0 || row < BN) *reinterpret_cast<u32x4*>(&Bt[row * LD + 4 * (kcB ^ swz(row))]) = t.b[j];
             }
         }
     };
@@ -497,27 +507,22 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[s][i][j][r] = 0.f;
 
-    const int nkt = p.K / BK;
-    load_tile();
-    store_tile(0);
-    __syncthreads();
+    const int nkt = p.K / KT;
     const int a_row = wm * (BM / WM) + li;
     const int b_col = wn * (BN / WN) + li;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile();          // buffer loads in flight under the MFMAs
+    auto mma_tile = [&](int cur) {
         const float* A = As + cur * A_SZ;
         const float* Bt = Bs + cur * B_SZ;
         if constexpr (BF16) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {            // two k-steps of 16; lane half lh supplies k = 16 q + 8 lh + [0, 8)
+            for (int q = 0; q < KT / 16; ++q) {      // k-steps of 16; lane half lh supplies k = 16 q + 8 lh + [0, 8)
                 LV8 a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    a[i] = *reinterpret_cast<const LV8*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ (((a_row + i * 32) >> 1) & 3))]);
+                    a[i] = *reinterpret_cast<const LV8*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ swz(a_row + i * 32))]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    b[j] = *reinterpret_cast<const LV8*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ (((b_col + j * 32) >> 1) & 3))]);
+                    b[j] = *reinterpret_cast<const LV8*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ swz(b_col + j * 32))]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -528,23 +533,55 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 a[TM], b[TN];
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    a[i] = *reinterpret_cast<const f32x4*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ (((a_row + i * 32) >> 1) & 7))]);
-    #pragma unroll
+                    a[i] = *reinterpret_cast<const f32x4*>(&A[(a_row + i * 32) * LD + 4 * ((2 * q + lh) ^ swz(a_row + i * 32))]);
+#pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    b[j] = *reinterpret_cast<const f32x4*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ (((b_col + j * 32) >> 1) & 7))]);
-    #pragma unroll
+                    b[j] = *reinterpret_cast<const f32x4*>(&Bt[(b_col + j * 32) * LD + 4 * ((2 * q + lh) ^ swz(b_col + j * 32))]);
+#pragma unroll
                 for (int t = 0; t < 4; ++t)
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < TM; ++i)
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < TN; ++j)
                             acc[t % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[t % NACC][i][j], 0, 0, 0);
             }
         }
-        if (kt + 1 < nkt) store_tile(cur ^ 1);  // the other buffer was last read one iteration ago (barrier below)
+    };
+
+    if constexpr (BF16) {
+        // 16-bit MFMAs finish a 32-deep tile in a quarter of the fp32 time, far less than a trip to L2 / HBM: the loads run TWO
+        // tiles ahead (two register stages, the loop unrolled by two so that their names are static), LDS stays double buffered
+        Stage t0, t1;
+        load_tile(t0, true);
+        load_tile(t1, 1 < nkt);
+        store_tile(0, t0);
         __syncthreads();
+        int kt = 0;
+        for (; kt + 1 < nkt; kt += 2) {              // straight-line body: no early exit between the two halves
+            load_tile(t0, kt + 2 < nkt);             // LDS[0] = tile kt, t1 = tile kt + 1 (in flight), t0 <- tile kt + 2
+            mma_tile(0);
+            store_tile(1, t1);
+            __syncthreads();
+            load_tile(t1, kt + 3 < nkt);             // LDS[1] = tile kt + 1, t0 = tile kt + 2 (in flight), t1 <- tile kt + 3
+            mma_tile(1);
+            store_tile(0, t0);                       // (zeros when tile kt + 2 does not exist)
+            __syncthreads();
+        }
+        if (kt < nkt) mma_tile(0);                   // odd tile count: the last tile sits in LDS[0]
+    } else {
+        Stage t0;
+        load_tile(t0, true);
+        store_tile(0, t0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) load_tile(t0, true);   // buffer loads in flight under the MFMAs
+            mma_tile(cur);
+            if (kt + 1 < nkt) store_tile(cur ^ 1, t0);   // the other buffer was last read one iteration ago (barrier below)
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int s = 1; s < NACC; ++s)
@@ -587,9 +624,10 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
     }
 }
 
-template <int BM, int BN, int WM, int WN, int PREC = 0>
-__global__ __launch_bounds__(WM * WN * 64) void conv_fast_kernel(ConvParams p) {
-    conv_fast_body<BM, BN, WM, WN, PREC>(p, blockIdx.x, gridDim.x);
+// (the 128 x 64 tile with 64-channel K tiles needs 48 KB of LDS: three blocks fit a CU if the registers allow three waves per SIMD)
+template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false, int KT = BK>
+__global__ __launch_bounds__(WM * WN * 64, (KT == 64 && BM * BN == 128 * 64) ? 3 : 1) void conv_fast_kernel(ConvParams p) {
+    conv_fast_body<BM, BN, WM, WN, PREC, IN16, KT>(p, blockIdx.x, gridDim.x);
 }
 // up to 4 independent convolutions of one tile configuration in a single launch (blockIdx.y selects the problem): the
 // parity classes of a strided convolution's data gradient are each too small to fill 256 CUs
@@ -598,16 +636,16 @@ struct ConvBatch { ConvParams p[4]; int nblk[4]; };
 // MFMA with fp32 accumulation (activations, weights and weight gradients stay fp32 in HBM) -- mmseg_set_conv_precision
 static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
 // which kernel template the last convolution entry point launched (mmseg_conv2d_last_kernel): family * 1000000 + 500000 * flag +
-// M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
+// M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / 16-bit input of the fast kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
 // 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel
 static int g_last_kernel = 0;
 #define MMSEG_SET_LAST(fam, bm, bn) (g_last_kernel = (fam) * 1000000 + (bm) * 1000 + (bn))
-template <int BM, int BN, int WM, int WN, int PREC = 0>
+template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fast_batched_kernel(ConvBatch pb) {
     const int z = blockIdx.y;
     const int nb = pb.nblk[z];
     if ((int)blockIdx.x >= nb) return;
-    conv_fast_body<BM, BN, WM, WN, PREC>(pb.p[z], blockIdx.x, nb);
+    conv_fast_body<BM, BN, WM, WN, PREC, IN16>(pb.p[z], blockIdx.x, nb);
 }
 template <int BM, int BN, int WM, int WN>
 static int launch_fast_batched(ConvBatch& pb, int n, hipStream_t st) {
@@ -619,17 +657,43 @@ static int launch_fast_batched(ConvBatch& pb, int n, hipStream_t st) {
         if (pb.nblk[z] > mx) mx = pb.nblk[z];
     }
     for (int z = n; z < 4; ++z) pb.nblk[z] = 0;
-    if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN, 1>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
+    const bool in16 = g_conv_bf16 != 0 && (pb.p[0].io & 1);      // every problem of a batch shares the storage type of its input
+    for (int z = 1; z < n; ++z)
+        if ((pb.p[z].io & 1) != (pb.p[0].io & 1)) return (int)hipErrorInvalidValue;
+    if (in16) g_last_kernel += 500000;
+    const dim3 grid(mx, n), block(WM * WN * 64);
+    if (g_conv_bf16 == 1 && in16) hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN, 1, true>), grid, block, 0, st, pb);
+    else if (g_conv_bf16 == 2 && in16) hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN, 2, true>), grid, block, 0, st, pb);
+    else if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN, 1>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
     else if (g_conv_bf16 == 2) hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN, 2>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
     else hipLaunchKernelGGL((conv_fast_batched_kernel<BM, BN, WM, WN>), dim3(mx, n), dim3(WM * WN * 64), 0, st, pb);
     return MMSEG_CHECK_LAUNCH();
 }
 
+// MMSEG_FAST_K64=0 keeps the 16-bit kernels on 32-channel K tiles (A/B measurements)
+static bool fast_k64_enabled() {
+    static const bool on = [] { const char* e = getenv("MMSEG_FAST_K64"); return !(e && e[0] == '0'); }();
+    return on;
+}
 template <int BM, int BN, int WM, int WN>
 static int launch_fast(const ConvParams& p, hipStream_t st) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.Cout + BN - 1) / BN;
     MMSEG_SET_LAST(1, BM, BN);
-    if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, 1>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
+    const bool in16 = g_conv_bf16 != 0 && (p.io & 1);
+    if (in16) g_last_kernel += 500000;                  // the 16-bit-input instantiation
+    // 16-bit tensors: 64-channel K tiles where a tile still lies inside one tap of one input tensor (with fp32 sources the
+    // doubled staging registers cost occupancy: measured slower on the 64-output-channel layers)
+    const bool k64 = in16 && BM * BN >= 128 * 64 && p.C1 % 64 == 0 && p.C2 % 64 == 0 && fast_k64_enabled();
+    if (k64) {
+        g_last_kernel += 250000;
+        const dim3 grid(ntm * ntn), block(WM * WN * 64);
+        if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, 1, true, 64>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, 2, true, 64>), grid, block, 0, st, p);
+        return MMSEG_CHECK_LAUNCH();
+    }
+    if (g_conv_bf16 == 1 && in16) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, 1, true>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
+    else if (g_conv_bf16 == 2 && in16) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, 2, true>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
+    else if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, 1>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
     else if (g_conv_bf16 == 2) hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN, 2>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
     else hipLaunchKernelGGL((conv_fast_kernel<BM, BN, WM, WN>), dim3(ntm * ntn), dim3(WM * WN * 64), 0, st, p);
     return MMSEG_CHECK_LAUNCH();
@@ -714,6 +778,7 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     const long tiles_big = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     const long lim = (1L << 31) - 64;
     const bool fast = p.wt != nullptr && aligned16(p.wt) && vec && !p.transposed && (p.C1 % 32 == 0) && (p.C2 % 32 == 0) && (p.Cout % 4 == 0) && aligned16(p.w) &&
+                      p.KH * p.KW <= 32 &&                  // one validity bit per tap and row
                       (long)p.B * p.H1 * p.W1 * p.C1 * 4 < lim && (long)p.B * p.H * p.W * p.C2 * 4 < lim &&
                       (long)p.K * p.Cout * 4 < lim;
     const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
@@ -1595,9 +1660,16 @@ __global__ void wflip_kernel(const float* __restrict__ w, float* __restrict__ wt
     }
 }
 
+// element i of a fast-path weight image: fp32, or -- in the reduced-precision modes -- the MFMA operand type itself (rounded once
+// here instead of on every staging pass of every block; the image then occupies the first half of the fp32-sized buffer)
+__device__ __forceinline__ void wimg_store(float* out, size_t i, float v, int prec) {
+    if (prec == 1) reinterpret_cast<__bf16*>(out)[i] = (__bf16)v;
+    else if (prec == 2) reinterpret_cast<_Float16*>(out)[i] = (_Float16)v;
+    else out[i] = v;
+}
 // mode 0 as a tiled transpose: per tap the [Cin][Cout] matrix goes to rows co of out[Cout][ntaps * Cin] at column tap*Cin + ci;
 // 32 x 32 tiles through LDS, so both the reads (along co) and the writes (along ci) are coalesced
-__global__ void wprep_fwd_tiled_kernel(const float* __restrict__ w, float* __restrict__ out, int ntaps, int Cin, int Cout) {
+__global__ void wprep_fwd_tiled_kernel(const float* __restrict__ w, float* __restrict__ out, int ntaps, int Cin, int Cout, int prec) {
     __shared__ float t[32][33];
     const int tap = blockIdx.z;
     const float* src = w + (size_t)tap * Cin * Cout;
@@ -1611,38 +1683,42 @@ __global__ void wprep_fwd_tiled_kernel(const float* __restrict__ w, float* __res
     const size_t K = (size_t)ntaps * Cin;
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
-        if (co < Cout && ci < Cin) out[(size_t)co * K + (size_t)tap * Cin + ci] = t[tx][r];
+        if (co < Cout && ci < Cin) wimg_store(out, (size_t)co * K + (size_t)tap * Cin + ci, t[tx][r], prec);
     }
 }
 
 // weight re-layouts for the fast path: out[n][tap'][c] with n the GEMM column (output channel of the launch)
 //   mode 0 (forward)      : out[co][tap][ci] = w[tap][ci][co]
 //   mode 1 (data gradient): out[ci][tap][co] = w[ntaps-1-tap][ci][co]
-__global__ void wprep_kernel(const float* __restrict__ w, float* __restrict__ out, int ntaps, int Cin, int Cout, int mode) {
+//   mode 2 (as is)        : out[i] = w[i] -- a kernel whose Keras layout already is the image (the all-taps 1x1 GEMM of the small-channel
+//                           data gradient), converted to the image's element type
+__global__ void wprep_kernel(const float* __restrict__ w, float* __restrict__ out, int ntaps, int Cin, int Cout, int mode, int prec) {
     const long n = (long)ntaps * Cin * Cout;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        if (mode == 0) {
+        if (mode == 2) {
+            wimg_store(out, i, w[i], prec);
+        } else if (mode == 0) {
             const int ci = i % Cin; long r = i / Cin;
             const int tap = r % ntaps; const int co = r / ntaps;
-            out[i] = w[((long)tap * Cin + ci) * Cout + co];
+            wimg_store(out, i, w[((long)tap * Cin + ci) * Cout + co], prec);
         } else {
             const int co = i % Cout; long r = i / Cout;
             const int tap = r % ntaps; const int ci = r / ntaps;
-            out[i] = w[((long)(ntaps - 1 - tap) * Cin + ci) * Cout + co];
+            wimg_store(out, i, w[((long)(ntaps - 1 - tap) * Cin + ci) * Cout + co], prec);
         }
     }
 }
 
 // sub-kernel of parity class (ph, pw): out[ci][(th, tw)][co] = w[ph + s*(TH-1-th)][pw + s*(TW-1-tw)][ci][co]
 __global__ void wprep_parity_kernel(const float* __restrict__ w, float* __restrict__ out, int KH, int KW, int Cin, int Cout,
-                                    int TH, int TW, int s, int ph, int pw) {
+                                    int TH, int TW, int s, int ph, int pw, int prec) {
     const long n = (long)TH * TW * Cin * Cout;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int co = i % Cout; long r = i / Cout;
         const int tw = r % TW; r /= TW;
         const int th = r % TH; const int ci = r / TH;
         const int kh = ph + s * (TH - 1 - th), kw = pw + s * (TW - 1 - tw);
-        out[i] = w[(((long)kh * KW + kw) * Cin + ci) * Cout + co];
+        wimg_store(out, i, w[(((long)kh * KW + kw) * Cin + ci) * Cout + co], prec);
     }
 }
 
@@ -1950,17 +2026,17 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
 int mmseg_conv2d_fast_path(int C1, int C2, int Cout, int transposed) {
     return (!transposed && C1 % 32 == 0 && C2 % 32 == 0 && Cout % 4 == 0) ? 1 : 0;
 }
-// mode 0: forward layout [Cout][KH*KW][Cin]; mode 1: data-gradient layout [Cin][KH*KW flipped][Cout]
+// mode 0: forward layout [Cout][KH*KW][Cin]; mode 1: data-gradient layout [Cin][KH*KW flipped][Cout]; mode 2: the kernel as it is
 int mmseg_conv2d_wprep(const float* w, float* out, int KH, int KW, int Cin, int Cout, int mode, void* stream) {
     const long n = (long)KH * KW * Cin * Cout;
     if (mode == 0 && KH * KW <= 65535) {
         const dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, KH * KW);
-        hipLaunchKernelGGL(wprep_fwd_tiled_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, out, KH * KW, Cin, Cout);
+        hipLaunchKernelGGL(wprep_fwd_tiled_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, out, KH * KW, Cin, Cout, g_conv_bf16);
         return MMSEG_CHECK_LAUNCH();
     }
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wprep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH * KW, Cin, Cout, mode);
+    hipLaunchKernelGGL(wprep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH * KW, Cin, Cout, mode, g_conv_bf16);
     return MMSEG_CHECK_LAUNCH();
 }
 // taps of parity class p along one axis: kh = p, p + s, ... < K
@@ -1971,7 +2047,7 @@ int mmseg_conv2d_wprep_parity(const float* w, float* out, int KH, int KW, int Ci
     const long n = (long)TH * TW * Cin * Cout;
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wprep_parity_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH, KW, Cin, Cout, TH, TW, stride, ph, pw);
+    hipLaunchKernelGGL(wprep_parity_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH, KW, Cin, Cout, TH, TW, stride, ph, pw, g_conv_bf16);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_conv2d_wflip(const float* w, float* wt, int KH, int KW, int Cin, int Cout, void* stream) {

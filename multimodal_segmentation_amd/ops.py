@@ -79,6 +79,8 @@ def set_conv_precision(mode):
     rounded to the 16-bit type, fp32 accumulation; tensors in HBM, weight gradients, normalisation, losses and the optimiser
     stay fp32).  Returns the previous mode."""
     old = N.call('mmseg_set_conv_precision', _PRECISIONS.index(mode))
+    if _PRECISIONS[old] != mode:
+        bump_weight_version()           # the fast-path weight images hold elements of the operand type: cached ones are stale
     return _PRECISIONS[old]
 
 
@@ -267,7 +269,9 @@ class _Conv2d(torch.autograd.Function):
                 nt = KH * KW * Cin
                 T = _ws('dgrad_taps', B * Ho * Wo * nt, dy.device)[:B * Ho * Wo * nt]
                 # the Keras kernel [KH, KW, Cin, Cout] read as [taps * Cin][Cout] IS the fast layout of that 1x1 convolution
-                N.call('mmseg_conv2d_fwd', g, None, None, w.reshape(-1), None, T, None, B, Ho, Wo, Cout, 0, Ho, Wo, nt, 1, 1, 1, 0, 0,
+                # (in the reduced-precision modes the image holds 16-bit elements: converted copy, cached like the other images)
+                wimg = w.reshape(-1) if N.call('mmseg_get_conv_precision') == 0 else _wprep(w, KH, KW, Cin, Cout, 2, ctx.wkey)
+                N.call('mmseg_conv2d_fwd', g, None, None, wimg, None, T, None, B, Ho, Wo, Cout, 0, Ho, Wo, nt, 1, 1, 1, 0, 0,
                        0, 0, 0, 0.0, 0)
                 N.call('mmseg_conv2d_dgrad_tapsum', T, d1, B, H, W, Ho, Wo, Cin, KH, KW, ph, pw)
             elif tr and stride == 2 and C2 == 0 and not ups and N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0) and \
