@@ -1444,8 +1444,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
         d_off[it] = (pbeg + 4 * pg) * p.Cout + n0 + d_cw * cq;
     }
 
-    u32x4 ra[A_IT][4], rdv[D_IT][4];
-    auto load_stage = [&](int ps) {
+    struct WStage { u32x4 a[A_IT][4]; u32x4 d[D_IT][4]; };       // a stage in flight as raw bits
+    // (a stage at or beyond `pend` loads nothing: every pixel test fails, the offsets are out of range)
+    auto load_stage = [&](WStage& t, int ps) {
+        u32x4 (&ra)[A_IT][4] = t.a;
+        u32x4 (&rdv)[D_IT][4] = t.d;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int hi = a_ho[it] * p.stride + a_dh[it];
@@ -1475,7 +1478,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
             d_off[it] += PT * p.Cout;
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, const WStage& t) {
+        const u32x4 (&ra)[A_IT][4] = t.a;
+        const u32x4 (&rdv)[D_IT][4] = t.d;
         float* A = Ap + buf * A_SZ;
         float* D = Dp + buf * D_SZ;
 #pragma unroll
@@ -1526,9 +1531,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
                 for (int r = 0; r < 16; ++r) acc[s][i][j][r] = 0.f;
 
     if (pbeg < pend) {
-        load_stage(pbeg);
-        store_stage(0);
-        __syncthreads();
         const int ar = wm * (BKT / WM) + li, br = wn * (BNT / WN) + li;
         int a_s0[TM], a_f[TM], b_s0[TN], b_f[TN];        // 16-bit image: slot of chunk 0 + XOR term of this lane's operand rows
         if constexpr (LP) {
@@ -1537,10 +1539,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
 #pragma unroll
             for (int j = 0; j < TN; ++j) b_s0[j] = d16 ? lp_row_slot<BNT, 8>(br + j * 32, b_f[j]) : lp_row_slot<BNT, 4>(br + j * 32, b_f[j]);
         }
-        int cur = 0;
-        for (int ps = pbeg; ps < pend; ps += PT) {
-            const bool more = ps + PT < pend;
-            if (more) load_stage(ps + PT);               // buffer loads in flight under the MFMAs
+        auto mma_stage = [&](int cur) {
             const float* A = Ap + cur * A_SZ;
             const float* D = Dp + cur * D_SZ;
             if constexpr (LP) {
@@ -1578,9 +1577,41 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
                                 acc[t % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[t % NACC][i][j], 0, 0, 0);
                 }
             }
-            if (more) store_stage(cur ^ 1);
+        };
+        if constexpr (LP) {
+            // 16-bit MFMAs finish a 32-pixel stage in a quarter of the fp32 time: the loads run TWO stages ahead (two register
+            // sets, the loop unrolled by two so that their names are static and the compiler's vmcnt waits are exact)
+            WStage t0, t1;
+            load_stage(t0, pbeg);
+            load_stage(t1, pbeg + PT);
+            store_stage(0, t0);
             __syncthreads();
-            cur ^= 1;
+            int ps = pbeg;
+            for (; ps + PT < pend; ps += 2 * PT) {
+                load_stage(t0, ps + 2 * PT);             // LDS[0] = stage ps, t1 = stage ps + PT (in flight)
+                mma_stage(0);
+                store_stage(1, t1);
+                __syncthreads();
+                load_stage(t1, ps + 3 * PT);             // LDS[1] = stage ps + PT, t0 = stage ps + 2 PT (in flight)
+                mma_stage(1);
+                store_stage(0, t0);                      // (zeros when that stage lies beyond the chunk)
+                __syncthreads();
+            }
+            if (ps < pend) mma_stage(0);                 // odd stage count: the last one sits in LDS[0]
+        } else {
+            WStage t0;
+            load_stage(t0, pbeg);
+            store_stage(0, t0);
+            __syncthreads();
+            int cur = 0;
+            for (int ps = pbeg; ps < pend; ps += PT) {
+                const bool more = ps + PT < pend;
+                if (more) load_stage(t0, ps + PT);       // buffer loads in flight under the MFMAs
+                mma_stage(cur);
+                if (more) store_stage(cur ^ 1, t0);
+                __syncthreads();
+                cur ^= 1;
+            }
         }
     }
 #pragma unroll

@@ -7,6 +7,7 @@ fixed synthetic validation split of 256 paired slices.
 
     python tools/dice_seeds.py <seed> <product|oracle> [iterations=500] [size=64] [batch=4] [lr=1e-3] [swa_from=350] [swa_every=10]
     python tools/dice_seeds.py summary <log> [<log> ...]        # mean +- 95 % CI of (product - oracle) over the seeds
+    DICE_CHECKS=10,25,50,100,200 python tools/dice_seeds.py ...  # also evaluate the LIVE model after these iterations (CHECK lines)
 
 One line `RESULT seed side dice_mod1 dice_mod2 dice_mean` is printed at the end of a run; `summary` pairs the lines by seed.
 """
@@ -19,7 +20,30 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
+def trajectory(paths):
+    """|Dice(product) - Dice(oracle)| of the live model at the check points (DICE_CHECKS): the two trajectories start from the
+    same weights and see the same batches, so early check points test the implementation; the chaotic growth of the fp32
+    rounding differences shows up as the gap widening with the iteration count"""
+    chk = {}
+    for p in paths:
+        for line in open(p):
+            if line.startswith('CHECK'):
+                _, seed, side, it, d1, d2, dm = line.split()
+                chk.setdefault(int(it), {}).setdefault(int(seed), {})[side] = (float(d1), float(d2), float(dm))
+    if not chk:
+        return
+    print('iteration   seeds   mean Dice product / oracle    mean |delta| (per modality)   max |delta|')
+    for it in sorted(chk):
+        rows = [v for v in chk[it].values() if 'product' in v and 'oracle' in v]
+        if not rows:
+            continue
+        d = np.array([[abs(r['product'][0] - r['oracle'][0]), abs(r['product'][1] - r['oracle'][1])] for r in rows])
+        print('%9d   %5d   %.4f / %.4f               %.5f                       %.5f' % (
+            it, len(rows), np.mean([r['product'][2] for r in rows]), np.mean([r['oracle'][2] for r in rows]), d.mean(), d.max()))
+
+
 def summary(paths):
+    trajectory(paths)
     res = {}
     for p in paths:
         for line in open(p):
@@ -65,6 +89,7 @@ def main():
     arg = lambda i, d, t: t(sys.argv[i]) if len(sys.argv) > i else d
     iters, H, B, lr = arg(3, 500, int), arg(4, 64, int), arg(5, 4, int), arg(6, 1e-3, float)
     swa_from, swa_every = arg(7, 350, int), arg(8, 10, int)
+    checks = set(int(v) for v in os.environ.get('DICE_CHECKS', '').split(',') if v)     # iterations after which the live model is evaluated
     odt = torch.float32                                   # the oracle runs in fp32 here (CPU time); the product is fp32 too
     torch.set_num_threads(int(os.environ.get('ORACLE_THREADS', max(1, min(len(os.sched_getaffinity(0)), 16)))))
     if side == 'oracle':                                  # no GPU: build the identically seeded model on the CPU stand-in to export weights
@@ -127,6 +152,21 @@ def main():
                 swa[k] = (swa[k] * n_swa + cur[k]) / (n_swa + 1)
             n_swa += 1
 
+    def evaluate_live():
+        """Dice of the LIVE weights (inference-mode BatchNorm) on the validation split: the trajectory check points"""
+        x1, x2 = val.get_images_modi(0), val.get_images_modi(1)
+        m1, m2 = val.get_masks_modi(0), val.get_masks_modi(1)
+        out = []
+        for i, (x, m) in enumerate(((x1, m1), (x2, m2))):
+            if side == 'oracle':
+                with torch.no_grad():
+                    preds = [OM.segmentor(orc.enc(torch.as_tensor(x[j:j + 32], dtype=odt), i), orc.P, False, None).numpy()
+                             for j in range(0, len(x), 32)]
+            else:
+                preds = [model.Segmentor.predict(model.Encoders_Anatomy[i].predict(x[j:j + 32])) for j in range(0, len(x), 32)]
+            out.append(costs.dice(m, np.concatenate(preds, 0), binarise=True))
+        return out
+
     def evaluate_swa():
         x1, x2 = val.get_images_modi(0), val.get_images_modi(1)
         m1, m2 = val.get_masks_modi(0), val.get_masks_modi(1)
@@ -160,6 +200,11 @@ def main():
             swa_update()
         if it % 50 == 0 or it == iters - 1:
             print('seed %d %s iter %4d seg loss %.4f (%.0f s)' % (seed, side, it, loss, time.time() - t0), flush=True)
+        if it + 1 in checks:
+            c1, c2 = evaluate_live()
+            print('CHECK %d %s %d %.5f %.5f %.5f' % (seed, side, it + 1, c1, c2, 0.5 * (c1 + c2)), flush=True)
+    if swa is None:
+        return
     d1, d2 = evaluate_swa()
     print('RESULT %d %s %.5f %.5f %.5f' % (seed, side, d1, d2, 0.5 * (d1 + d2)), flush=True)
 
