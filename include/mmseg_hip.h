@@ -190,6 +190,11 @@ int mmseg_bn_bwd_t(const void* dy, const void* y, const void* x, const float* ga
 int mmseg_maxpool2_fwd_t(const void* x, void* y, int B, int H, int W, int C, int h, void* stream);
 int mmseg_maxpool2_bwd_t(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, int h, void* stream);
 int mmseg_upsample2_bwd_t(const void* dy, void* dx, int B, int H, int W, int C, int h, void* stream);
+/* dx = dy * act'(y) of a convolution's fused activation (y = its output), tensors stored with element code h (0 fp32, 1 bf16, 2 fp16);
+ * with bias_grad != NULL also the bias gradient bias_grad[c] (+)= sum_m dx[m][c] in the same pass (C % 64 == 0, ws =
+ * mmseg_colsum_workspace_floats(M, C) floats) -- one pass instead of mmseg_act_bwd + mmseg_colsum */
+int mmseg_act_bwd_bias_t(const void* dy, const void* y, void* dx, float* bias_grad, float* ws, long M, int C, int act, float alpha,
+                         int accumulate, int h, void* stream);
 /* keras_contrib InstanceNormalization(axis=None) fused with SPADE_COND and LeakyReLU (layers/spade.py:7-33,51-54) */
 int mmseg_in_workspace_floats(int B);
 int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float* ws, int B,

@@ -240,6 +240,73 @@ static inline int grid16(long n) {
     if (b < 1) b = 1;
     return (int)b;
 }
+
+// ---- activation gradient (+ bias gradient) --------------------------------------------------------------------------------------
+// dx = dy * act'(y) of a convolution's fused activation (y = its OUTPUT), all three tensors stored with element code H; with
+// `part` also the per-block column sums of dx -- the bias gradient of that convolution -- in the same pass (one read of dy and y,
+// one write of dx, instead of act_bwd followed by a column-sum pass over dx).  C % 64 == 0; grid (row blocks, C/64), block = 16
+// float4 column lanes x 16 row lanes; deterministic two-stage reduction as mmseg_colsum.
+template <int H, bool SUM>
+__global__ __launch_bounds__(256) void act16_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ y, void* __restrict__ dx,
+                                                        float* __restrict__ part, long M, int C, long rows_per_block, int act, float alpha) {
+    __shared__ f32x4 sm[16][16];
+    const int tid = threadIdx.x, c4 = tid & 15, rl = tid >> 4;
+    const int C4 = C >> 2, col = blockIdx.y * 16 + c4;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (long r = r0 + rl; r < r1; r += 16) {
+        const f32x4 g = ld4<H>(dy, r * C4 + col), o = ld4<H>(y, r * C4 + col);
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = g[e] * act_grad_from_out(o[e], act, alpha);
+        st4<H>(dx, r * C4 + col, d);
+        if (SUM) {
+            if (H != 0) {                      // the bias gradient sums what the weight / data gradients will read: the stored values
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = H == 1 ? (float)(__bf16)d[e] : (float)(_Float16)d[e];
+            }
+            s += d;
+        }
+    }
+    if (SUM) {
+        sm[rl][c4] = s;
+        __syncthreads();
+        if (tid < 16) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += sm[k][tid];
+            *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + (size_t)(blockIdx.y * 16 + tid) * 4) = t;
+        }
+    }
+}
+// out[c] (+)= sum over the row blocks of part[b][c]; one block per channel, fixed order
+__global__ __launch_bounds__(256) void colsum16_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C,
+                                                             int accumulate) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float a = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) a += part[(size_t)b * C + c];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + red[0] : red[0];
+}
+// element-wise form for any n (n % 4 == 0): no bias gradient
+template <int H>
+__global__ void act16_bwd_flat_kernel(const void* __restrict__ dy, const void* __restrict__ y, void* __restrict__ dx, long n4, int act, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 g = ld4<H>(dy, i), o = ld4<H>(y, i);
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = g[e] * act_grad_from_out(o[e], act, alpha);
+        st4<H>(dx, i, d);
+    }
+}
+
 static inline bool hcode_ok(int h) { return h >= 0 && h <= 2; }
 // (hx, hy) pairs that occur: a tensor is fp32 or THE 16-bit type of the run
 #define DISPATCH_HH(hx, hy, LAUNCH)                                              \
@@ -322,6 +389,36 @@ int mmseg_upsample2_bwd_t(const void* dy, void* dx, int B, int H, int W, int C, 
 #define L(HH) hipLaunchKernelGGL((upsample16_bwd_kernel<HH>), dim3(grid16(n)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, C / 4)
     DISPATCH_H(h, L);
 #undef L
+    return MMSEG_CHECK_LAUNCH();
+}
+
+
+// dx = dy * act'(y) (y = the activation's output; codes as mmseg_act_fwd), dy / y / dx stored with element code h; with bias_grad != NULL
+// also bias_grad[c] (+)= sum over the M rows of dx[., c] in the same pass (needs C % 64 == 0 and ws = mmseg_colsum_workspace_floats(M, C)
+// floats); otherwise M * C % 4 == 0 suffices.  Replaces act_bwd + colsum of a convolution with a fused activation and a bias.
+int mmseg_act_bwd_bias_t(const void* dy, const void* y, void* dx, float* bias_grad, float* ws, long M, int C, int act, float alpha,
+                         int accumulate, int h, void* stream) {
+    if (!hcode_ok(h) || M <= 0 || C <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    if (bias_grad == nullptr) {
+        const long n = M * C;
+        if (n % 4 != 0) return (int)hipErrorInvalidValue;
+#define L(HH) hipLaunchKernelGGL((act16_bwd_flat_kernel<HH>), dim3(grid16(n / 4)), dim3(256), 0, st, dy, y, dx, n / 4, act, alpha)
+        DISPATCH_H(h, L);
+#undef L
+        return MMSEG_CHECK_LAUNCH();
+    }
+    if (C % 64 != 0 || ws == nullptr) return (int)hipErrorInvalidValue;
+    long nb = 1024 / (C / 64);
+    if (nb > 512) nb = 512;
+    const long maxb = (M + 63) / 64;
+    if (nb > maxb) nb = maxb;
+    if (nb < 1) nb = 1;
+    const long rpb = (M + nb - 1) / nb;
+#define L(HH) hipLaunchKernelGGL((act16_bwd_kernel<HH, true>), dim3((unsigned)nb, C / 64), dim3(256), 0, st, dy, y, dx, ws, M, C, rpb, act, alpha)
+    DISPATCH_H(h, L);
+#undef L
+    hipLaunchKernelGGL(colsum16_final_kernel, dim3(C), dim3(256), 0, st, (const float*)ws, bias_grad, (int)nb, C, accumulate);
     return MMSEG_CHECK_LAUNCH();
 }
 

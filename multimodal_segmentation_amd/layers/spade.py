@@ -32,10 +32,19 @@ def declare_spade_decoder(m, conf):
     return SPADE_BLOCKS[-1][1]
 
 
+def spade_hidden(m, name, a):
+    """the unit's shared 3x3 convolution + ReLU (layers/spade.py:28-29).  Its 128-channel output is by far the largest tensor of the
+    decoder (1.6 GB per unit in fp32 at 256 x 256 with the 48 decoder passes of an iteration batched); with conf.act_storage = 'half' it and its gradient live
+    in HBM as 16-bit tensors (the gamma / beta convolutions and their gradients read / write them as such)."""
+    import torch
+    half = ops.act16_dtype()
+    return nn.conv(m, name + '_shared', a, act='relu', out_dtype=half if half is not None else torch.float32)
+
+
 def _spade(m, name, anatomy_input, layer, act_alpha):
     """layers/spade.py:26-33 (+ the LeakyReLU that follows it in spade_block when act_alpha >= 0)"""
     a = ops.resize_nearest_down(anatomy_input, layer.shape[1], layer.shape[2])
-    a = nn.conv(m, name + '_shared', a, act='relu')
+    a = spade_hidden(m, name, a)
     gamma = nn.conv(m, name + '_gamma', a)
     beta = nn.conv(m, name + '_beta', a)
     return ops.instnorm_spade(layer, gamma, beta, act_alpha)

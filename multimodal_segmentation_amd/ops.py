@@ -207,7 +207,6 @@ class _Conv2d(torch.autograd.Function):
         Ho, Wo, ph, pw = _conv_geometry(H, W, KH, KW, stride, padding)
         y = _new((B, Ho, Wo, Cout), x1, out_dtype)
         wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
-        assert not (ACT[act] and out_dtype != torch.float32), 'a fused activation needs an fp32 output (its backward kernel is fp32)'
         _conv_fwd_raw(x1, x2, w, wt, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,
                       ACT[act], alpha, 0)
         ctx.geom = (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), ACT[act], alpha)
@@ -222,15 +221,25 @@ class _Conv2d(torch.autograd.Function):
         w = ctx.w
         B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, act, alpha = ctx.geom
         dy = _c(dy)
+        M = B * Ho * Wo
+        bias_done = False
         if act:
             g = _new(dy.shape, dy)
-            N.call('mmseg_act_bwd', dy, y, g, dy.numel(), act, float(alpha))
+            assert _h(dy) == _h(y), 'the gradient of a tensor is stored like the tensor'
+            if ctx.bgrad is not None and Cout % 64 == 0:
+                # activation gradient and bias gradient (column sums of g) in one pass over dy / y
+                ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', M, Cout), dy.device)
+                N.call('mmseg_act_bwd_bias_t', dy, y, g, ctx.bgrad, ws, M, Cout, act, float(alpha), 1, _h(dy))
+                bias_done = True
+            elif _h(dy):
+                N.call('mmseg_act_bwd_bias_t', dy, y, g, None, None, M, Cout, act, float(alpha), 0, _h(dy))
+            else:
+                N.call('mmseg_act_bwd', dy, y, g, dy.numel(), act, float(alpha))
         else:
             g = dy
         need_x1, need_x2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx1 = dx2 = None
-        M = B * Ho * Wo
-        if ctx.bgrad is not None:
+        if ctx.bgrad is not None and not bias_done:
             ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', M, Cout), dy.device)
             N.call('mmseg_colsum', g if _h(g) == 0 else g.float(), ctx.bgrad, ws, M, Cout, 1.0, 1)
         if ctx.wgrad is not None:

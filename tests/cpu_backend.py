@@ -201,6 +201,15 @@ def act_bwd(dy, y, dx, n, act, alpha):
     dx.copy_(dy * _act_grad(y, act, alpha)); return 0
 
 
+def act_bwd_bias_t(dy, y, dx, bias_grad, ws, M, C, act, alpha, accumulate, h):
+    d = dy.float() * _act_grad(y.float(), act, alpha)
+    dx.copy_(d.to(dx.dtype))
+    if bias_grad is not None:
+        s = dx.float().reshape(M, C).sum(0)
+        bias_grad.copy_(bias_grad + s if accumulate else s)
+    return 0
+
+
 def axpby(a, b, out, n, sa, sb):
     out.copy_(a * sa + b * sb); return 0
 
