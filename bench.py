@@ -266,6 +266,8 @@ def main():
                     help='bf16: bf16 MFMA operands (fp32 accumulation, fp32 tensors in HBM, fp32 weight gradients) -- configs #3/#5')
     ap.add_argument('--act16', action='store_true',
                     help='with --dtype bf16 | f16: the activations / gradients of the MFMA trunk live in HBM in the 16-bit type (conf.act_storage = half)')
+    ap.add_argument('--graphs', action='store_true',
+                    help='conf.hip_graphs: every trainer step is recorded into a hipGraph after two eager steps and replayed (single GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
     ap.add_argument('--conv-breakdown', action='store_true', help='per-shape convolution table on stderr')
@@ -324,6 +326,10 @@ def main():
             raise SystemExit('--act16 needs --dtype bf16 or f16')
         cfg['act_storage'] = 'half'
         DTYPE_NAME[args.dtype] = DTYPE_NAME[args.dtype].replace('(fp32 accumulate)', '(fp32 accumulate), 16-bit trunk activations in HBM')
+    if args.graphs:
+        cfg['hip_graphs'] = True
+        args.no_conv_timer = True        # replayed launches do not pass through the Python call the timer hooks
+        DTYPE_NAME[args.dtype] += ', trainer steps replayed from hipGraphs'
     cfg['folder'] = '/tmp/mmseg_bench'
     conf = EasyDict(cfg)
 

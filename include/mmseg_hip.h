@@ -265,6 +265,8 @@ int mmseg_diffloss_grad(const float* p, const float* t, float tconst, long n, in
 /* ---- optimiser / regulariser (csrc/optim.hip) ---------------------------------------------------------- */
 /* Keras 2.1.6 Adam step over a flat arena (models/dafnet.py:93,114,155,161) */
 int mmseg_adam(float* p, const float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, void* stream);
+/* the same update with lr_t read from device memory (one float) -- the form recorded when a training step is captured into a hipGraph */
+int mmseg_adam_p(float* p, const float* g, float* m, float* v, long n, const float* lr_t, float b1, float b2, float eps, void* stream);
 /* layers/spectralnorm.py:199-239 */
 long mmseg_spectral_workspace_floats(int K, int N);
 int mmseg_spectral_fwd(const float* w, const float* u0, float* loss, float* sgn, float* ws, int K, int N, float alpha, void* stream);

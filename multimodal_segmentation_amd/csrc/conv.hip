@@ -787,6 +787,11 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (!fast && p.w == nullptr) return (int)hipErrorInvalidValue;   // the generic kernels read the Keras-layout weights: a caller
                                                                      // that only prepared `wt` must not fall through to them
     if (fast) {
+        static const int force_tile = [] { const char* e = getenv("MMSEG_FAST_TILE"); return e ? atoi(e) : 0; }();   // tile A/B measurements
+        if (force_tile == 1) return launch_fast<128, 128, 2, 2>(p, st);
+        if (force_tile == 2) return launch_fast<128, 64, 2, 2>(p, st);
+        if (force_tile == 3) return launch_fast<64, 64, 2, 2>(p, st);
+        if (force_tile == 4) return launch_fast<128, 32, 4, 1>(p, st);
         if (p.Cout > 64 && tiles_big >= 384) return launch_fast<128, 128, 2, 2>(p, st);
         if (p.Cout > 32) {
             const long tiles_mid = (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64);

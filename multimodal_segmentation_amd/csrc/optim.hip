@@ -7,7 +7,10 @@
 #include "common.hpp"
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n4, long n, float lr_t, float b1, float b2, float eps) {
+                            long n4, long n, float lr_host, const float* __restrict__ lr_dev, float b1, float b2, float eps) {
+    // lr_dev != NULL: the bias-corrected step size is read from device memory, so that a captured launch (hipGraph replay of a
+    // training step) sees the value of the step being replayed, not the one baked into the launch at capture time
+    const float lr_t = lr_dev ? lr_dev[0] : lr_host;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
         f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i], pp = reinterpret_cast<f32x4*>(p)[i];
@@ -198,7 +201,16 @@ int mmseg_adam(float* p, const float* g, float* m, float* v, long n, float lr_t,
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, lr_t, b1, b2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, lr_t, (const float*)nullptr, b1, b2, eps);
+    return MMSEG_CHECK_LAUNCH();
+}
+// the same update with lr_t read from device memory (one float): the form a hipGraph capture of a training step records
+int mmseg_adam_p(float* p, const float* g, float* m, float* v, long n, const float* lr_t, float b1, float b2, float eps, void* stream) {
+    if (lr_t == nullptr) return (int)hipErrorInvalidValue;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, n, 0.f, lr_t, b1, b2, eps);
     return MMSEG_CHECK_LAUNCH();
 }
 

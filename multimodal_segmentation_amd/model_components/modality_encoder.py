@@ -10,7 +10,7 @@ import logging
 import numpy as np
 import torch
 
-from .. import nn, ops
+from .. import graphs, nn, ops
 from ..utils.rng import global_rng
 
 log = logging.getLogger('modality_encoder')
@@ -53,7 +53,8 @@ class ModalityEncoder(nn.Model):
             if self._eps_rng is None:
                 from ..parallel import dp
                 self._eps_rng = np.random.RandomState((self._eps_seed + 7919 * dp.rank()) % (2 ** 32))
-            eps = self._eps_rng.normal(0., 1., size=tuple(z_mean.shape)).astype(np.float32)
+            shape = tuple(z_mean.shape)
+            eps = graphs.host_draw(lambda: self._eps_rng.normal(0., 1., size=shape).astype(np.float32), z_mean.device)
         eps = nn.to_device(eps, z_mean.device)
         z, kl = ops.sampling_kl(z_mean, z_log_var, eps)
         return [z, kl]

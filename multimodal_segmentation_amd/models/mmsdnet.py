@@ -65,6 +65,8 @@ class MMSDNet(BaseNet):
             t = getattr(self, name, None)
             if t is not None:
                 t.loss_scale = scale
+                # conf.hip_graphs (build-defined, default False): record each trainer step into a hipGraph and replay it (graphs.py)
+                t.use_graph = bool(self.conf.get('hip_graphs', False))
 
     def build(self):
         self.apply_compute_dtype()

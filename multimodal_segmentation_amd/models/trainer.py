@@ -9,7 +9,7 @@ Loss kinds (reference costs.py / keras): 'dice_bce' (make_combined_dice_bce), 'd
 """
 import torch
 
-from .. import nn, ops
+from .. import graphs, nn, ops
 from ..parallel import dp
 
 
@@ -36,6 +36,9 @@ class Trainer(object):
         self.all_models = list(all_models) or self.train_models
         self.device = self.train_models[0].device
         self.last_outputs = None
+        # conf.hip_graphs: record the step into a hipGraph after two eager warm-up steps and replay it from then on (graphs.py)
+        self.use_graph = False
+        self._graphs = {}
         # static loss scale (fp16 compute mode): every seed gradient is multiplied by it, the gradient arenas are divided by it
         # before the optimiser step; 1.0 = off
         self.loss_scale = 1.0
@@ -75,8 +78,22 @@ class Trainer(object):
 
     def fit(self, inputs, targets, epochs=1, verbose=0, **graph_kw):
         assert epochs == 1
-        ins = [nn.to_device(x, self.device) for x in (inputs if isinstance(inputs, (list, tuple)) else [inputs])]
+        inputs = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
         targets = list(targets) if isinstance(targets, (list, tuple)) else [targets]
+        if self.use_graph and not graph_kw and not dp.enabled() and self.device.type == 'cuda':
+            key = graphs.signature(inputs, targets)
+            st = self._graphs.get(key)
+            if st is None:
+                st = self._graphs[key] = graphs.FitGraph(self)
+            return st.run(inputs, targets)
+        return self._fit_eager(inputs, targets, graph_kw)
+
+    @staticmethod
+    def _total(terms):
+        return nn_total(terms)
+
+    def _fit_eager(self, inputs, targets, graph_kw, lr_dev=None):
+        ins = [nn.to_device(x, self.device) for x in inputs]
         assert len(targets) == len(self.specs), '%s: %d targets for %d outputs' % (self.name, len(targets), len(self.specs))
         for m in self.train_models:
             m.zero_grad_own()
@@ -101,7 +118,7 @@ class Trainer(object):
         if self.loss_scale != 1.0:
             for m in self.train_models:
                 ops.axpby(m.grad_arena, m.grad_arena, 1.0 / self.loss_scale, 0.0, out=m.grad_arena)
-        self.optimizer.step(self.train_models)
+        self.optimizer.step(self.train_models, lr_dev=lr_dev)
         hist.record('loss', nn_total(terms))
         self.last_outputs = [o.detach() for o in outs]
         return hist

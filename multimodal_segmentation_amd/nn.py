@@ -385,10 +385,22 @@ class Adam(object):
         self.iterations = 0
         self.state = {}
 
-    def step(self, models):
-        self.iterations += 1
+    def _lr_t(self):
         t = self.iterations
-        lr_t = self.lr * math.sqrt(1. - self.beta_2 ** t) / (1. - self.beta_1 ** t)
+        return self.lr * math.sqrt(1. - self.beta_2 ** t) / (1. - self.beta_1 ** t)
+
+    def begin_device_step(self, device):
+        """graphs.py: advance the iteration count and put this step's lr_t into the device scalar the recorded Adam launches read"""
+        self.iterations += 1
+        if getattr(self, '_lr_dev', None) is None:
+            self._lr_dev = torch.empty(1, dtype=torch.float32, device=device)
+        ops.fill_(self._lr_dev, self._lr_t())
+        return self._lr_dev
+
+    def step(self, models, lr_dev=None):
+        if lr_dev is None:
+            self.iterations += 1
+        lr_t = self._lr_t() if lr_dev is None else lr_dev
         for m in models:
             st = self.state.get(id(m))
             if st is None:

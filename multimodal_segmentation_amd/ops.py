@@ -1094,7 +1094,10 @@ def spectral_reg_grad(w, sgn, scale=1.0):
 def adam_step(p, g, m, v, lr_t, beta_1=0.9, beta_2=0.999, eps=1e-7):
     """Keras 2.1.6 Adam over flat arenas (p, g, m, v: 1-D views of equal length)."""
     assert p.numel() == g.numel() == m.numel() == v.numel()
-    N.call('mmseg_adam', p, g, m, v, p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps))
+    if isinstance(lr_t, torch.Tensor):       # a device scalar: the launch stays valid when replayed from a captured graph
+        N.call('mmseg_adam_p', p, g, m, v, p.numel(), lr_t, float(beta_1), float(beta_2), float(eps))
+    else:
+        N.call('mmseg_adam', p, g, m, v, p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps))
     bump_weight_version()
 
 

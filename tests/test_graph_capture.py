@@ -1,0 +1,66 @@
+"""conf.hip_graphs (graphs.py): a trainer step replayed from a recorded hipGraph is bit-identical to the eager step -- weights, Adam
+state, BatchNorm moving statistics and every loss of five consecutive steps (two eager warm-up steps, the recording, two replays),
+for a discriminator trainer and for the full DAFNet generator trainer (whose sampling layer draws its noise on the host)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(hip_graphs, decoder='film'):
+    from multimodal_segmentation_amd import nn
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    conf = Hh.make_conf(dafnet_config_chaos, 64, hip_graphs=hip_graphs, decoder_type=decoder)
+    model = DAFNet(conf)
+    model.build()
+    return model
+
+
+def _state(models):
+    return [w.copy() for m in models for w in m.get_weights()]
+
+
+def test_discriminator_and_generator_steps_replayed_from_graphs_are_bitwise_the_eager_steps():
+    from tests import helpers as Hh
+    B, H, steps = 2, 64, 5
+    rng = np.random.RandomState(3)
+    data = [Hh.make_step_data(B, H, H, seed=40 + i) for i in range(steps)]
+    fake = [rng.rand(B, H, H, 4).astype(np.float32) for _ in range(steps)]
+    runs = {}
+    ref_w = None
+    for mode in (False, True):
+        model = _build(mode)
+        ms = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
+        if ref_w is None:
+            ref_w = [m.get_weights() for m in ms]
+        else:
+            for m, w in zip(ms, ref_w):
+                m.set_weights(w)
+        model.Enc_Modality._eps_rng = None            # both runs start the private noise stream from its seed
+        assert model.supervised_trainer.use_graph == mode and model.D_Mask_trainer.use_graph == mode
+        losses = []
+        B1 = np.ones((B, 1), np.float32)
+        for i in range(steps):
+            d = data[i]
+            h = model.D_Mask_trainer.fit([d['m1'][..., :4].copy(), fake[i]], [1.0, 0.0])
+            losses.append(('dm%d' % i, h.history['loss'][0]))
+            tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [B1] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [B1] * 4 + \
+                 [np.zeros(B, np.float32)] * 2 + [d['z1'], d['z2']]
+            h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg)
+            for k in h.history.keys():
+                losses.append(('g%d/%s' % (i, k), h.history[k][0]))
+        if mode:
+            g = model.supervised_trainer._graphs
+            assert len(g) == 1 and list(g.values())[0].graph is not None, 'the generator step was not recorded'
+            assert len(list(g.values())[0].draws) >= 2, 'the host draws of the sampling layer were not listed'
+        runs[mode] = (losses, _state(ms), model.supervised_trainer.optimizer.iterations)
+    (l0, w0, it0), (l1, w1, it1) = runs[False], runs[True]
+    assert it0 == it1 == steps
+    for (k0, v0), (k1, v1) in zip(l0, l1):
+        assert k0 == k1 and v0 == v1, 'loss %s: eager %r, graph %r' % (k0, v0, v1)
+    for a, b in zip(w0, w1):
+        assert np.array_equal(a, b)
