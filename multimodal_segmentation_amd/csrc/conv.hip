@@ -779,8 +779,8 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     const long lim = (1L << 31) - 64;
     const bool fast = p.wt != nullptr && aligned16(p.wt) && vec && !p.transposed && (p.C1 % 32 == 0) && (p.C2 % 32 == 0) && (p.Cout % 4 == 0) && aligned16(p.w) &&
                       p.KH * p.KW <= 32 &&                  // one validity bit per tap and row
-                      (long)p.B * p.H1 * p.W1 * p.C1 * 4 < lim && (long)p.B * p.H * p.W * p.C2 * 4 < lim &&
-                      (long)p.K * p.Cout * 4 < lim;
+                      (long)p.B * p.H1 * p.W1 * p.C1 * ((p.io & 1) ? 2 : 4) < lim && (long)p.B * p.H * p.W * p.C2 * ((p.io & 2) ? 2 : 4) < lim &&
+                      (long)p.K * p.Cout * 4 < lim;        // 32-bit buffer offsets (bytes of the tensors as they are stored)
     const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
     if (omap && !fast) return (int)hipErrorInvalidValue;     // strided output mapping exists on the fast path only
     if (!fast && (p.io & 3)) return (int)hipErrorInvalidValue;       // only the fast path reads 16-bit input tensors
@@ -2013,8 +2013,9 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
     const long KN = (long)p.K * Cout;
     const bool vec = (C1 % 4 == 0) && (C2 % 4 == 0) && aligned16(x1) && (C2 == 0 || aligned16(x2));
     const long lim = (1L << 31) - 64;
-    const bool fast = vec && (Cout % 4 == 0) && aligned16(dy) && (long)B * p.H1 * p.W1 * C1 * 4 < lim &&
-                      (long)B * H * W * C2 * 4 < lim && (long)p.M * Cout * 4 < lim;
+    const int esx = (io & 1) ? 2 : 4, esd = (io & 4) ? 2 : 4;      // bytes per stored element: 32-bit buffer offsets
+    const bool fast = vec && (Cout % 4 == 0) && aligned16(dy) && (long)B * p.H1 * p.W1 * C1 * esx < lim &&
+                      (long)B * H * W * C2 * esx < lim && (long)p.M * Cout * esd < lim;
     // transposed-staging kernel: 4 consecutive pixels of a thread's block lie in one output row
     const bool tr = fast && wgrad_tr_enabled() && stride == 1 && Wo % 4 == 0 && Ho > 32 / Wo && !(C1 == 8 && C2 == 0 && Cout == 8);
     int chunk;
