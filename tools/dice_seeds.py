@@ -42,7 +42,29 @@ def trajectory(paths):
             it, len(rows), np.mean([r['product'][2] for r in rows]), np.mean([r['oracle'][2] for r in rows]), d.mean(), d.max()))
 
 
+def weight_trajectory(paths):
+    """relative difference of the weight norm (segmentation path) between the two sides after n iterations: starts at the fp32
+    rounding level if one step is the same computation, and grows as the chaotic training dynamics amplify it"""
+    chk = {}
+    for p in paths:
+        for line in open(p):
+            if line.startswith('WCHECK'):
+                _, seed, side, it, n, nrm, sm = line.split()
+                chk.setdefault(int(it), {}).setdefault(int(seed), {})[side] = (float(nrm), float(sm), int(n))
+    if not chk:
+        return
+    print('iteration   seeds   |norm_p - norm_o| / norm_o (per seed)          |sum_p - sum_o| / norm_o (per seed)')
+    for it in sorted(chk):
+        rows = [v for _, v in sorted(chk[it].items()) if 'product' in v and 'oracle' in v]
+        if not rows:
+            continue
+        assert all(r['product'][2] == r['oracle'][2] for r in rows), 'the two sides count different numbers of weights'
+        print('%9d   %5d   %-45s  %s' % (it, len(rows), ' '.join('%.2e' % (abs(r['product'][0] - r['oracle'][0]) / r['oracle'][0]) for r in rows),
+                                          ' '.join('%.2e' % (abs(r['product'][1] - r['oracle'][1]) / r['oracle'][0]) for r in rows)))
+
+
 def summary(paths):
+    weight_trajectory(paths)
     trajectory(paths)
     res = {}
     for p in paths:
@@ -90,6 +112,7 @@ def main():
     iters, H, B, lr = arg(3, 500, int), arg(4, 64, int), arg(5, 4, int), arg(6, 1e-3, float)
     swa_from, swa_every = arg(7, 350, int), arg(8, 10, int)
     checks = set(int(v) for v in os.environ.get('DICE_CHECKS', '').split(',') if v)     # iterations after which the live model is evaluated
+    wchecks = set(int(v) for v in os.environ.get('DICE_WCHECKS', '').split(',') if v)   # ... after which the weight norm is printed
     odt = torch.float32                                   # the oracle runs in fp32 here (CPU time); the product is fp32 too
     torch.set_num_threads(int(os.environ.get('ORACLE_THREADS', max(1, min(len(os.sched_getaffinity(0)), 16)))))
     if side == 'oracle':                                  # no GPU: build the identically seeded model on the CPU stand-in to export weights
@@ -203,6 +226,18 @@ def main():
         if it + 1 in checks:
             c1, c2 = evaluate_live()
             print('CHECK %d %s %d %.5f %.5f %.5f' % (seed, side, it + 1, c1, c2, 0.5 * (c1 + c2)), flush=True)
+        if it + 1 in wchecks:
+            # a well-conditioned trajectory observable: L2 norm and sum of the weights of the segmentation path (float64 on the host).
+            # Kernels, gamma / beta and moving variances only: a convolution bias in front of a BatchNorm has an identically zero
+            # gradient (the product skips it, the reference and the oracle feed rounding noise through Adam into a random walk of
+            # that bias, which the BatchNorm -- and its moving mean -- absorbs without any effect on the output)
+            keep = lambda k: k.startswith(('EA0/', 'EA1/', 'EAS/', 'SEG/')) and k.endswith(('/kernel', '/gamma', '/beta', '/moving_variance'))
+            if side == 'oracle':
+                ws = [v.detach().double().numpy().ravel() for k, v in sorted(orc.P.items()) if keep(k)]
+            else:           # the same tensors under the oracle's names (the encoders' shared up-path counted once)
+                ws = [v.detach().double().cpu().numpy().ravel() for k, v in sorted(Hh.export_dafnet(model, torch.float32).items()) if keep(k)]
+            w = np.concatenate(ws)
+            print('WCHECK %d %s %d %d %.12e %.12e' % (seed, side, it + 1, w.size, np.sqrt((w * w).sum()), w.sum()), flush=True)
     if swa is None:
         return
     d1, d2 = evaluate_swa()
