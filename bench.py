@@ -51,8 +51,10 @@ def kernel_name(kid, prec):
     bm, bn = rest // 1000, rest % 1000
     wm, wn = (4, 1) if bn == 32 else (2, 2)
     tf = 'true' if flag else 'false'
-    if fam in (1, 4):          # <M tile, N tile, waves M, waves N, precision, 16-bit input, K tile>
+    if fam == 1:               # <M tile, N tile, waves M, waves N, precision, 16-bit input, K tile>
         return '%s<%d, %d, %d, %d, %d, %s, %d>' % (_FAMILY[fam], bm, bn, wm, wn, prec, tf, 64 if k64 else 32)
+    if fam == 4:
+        return '%s<%d, %d, %d, %d, %d, %s>' % (_FAMILY[fam], bm, bn, wm, wn, prec, tf)
     if fam == 7:
         return '%s<%d, %d, %d, %d, %d>' % (_FAMILY[fam], bm, bn, wm, wn, prec)
     if fam in (2, 8):
