@@ -57,7 +57,9 @@ def kernel_name(kid, prec):
         return '%s<%d, %d, %d, %d, %d, %s>' % (_FAMILY[fam], bm, bn, wm, wn, prec, tf)
     if fam == 7:
         return '%s<%d, %d, %d, %d, %d>' % (_FAMILY[fam], bm, bn, wm, wn, prec)
-    if fam in (2, 8):
+    if fam == 2:               # generic kernel: <..., 4-channel gather, precision> (16-bit MFMA variant only for forward launches)
+        return '%s<%d, %d, %d, %d, %s, %d>' % (_FAMILY[fam], bm, bn, wm, wn, tf, prec if k64 else 0)
+    if fam == 8:
         return '%s<%d, %d, %d, %d, %s>' % (_FAMILY[fam], bm, bn, wm, wn, tf)
     if fam == 6:
         return '%s<%d, %d, %d, %d, %d, %s>' % (_FAMILY[fam], bm, bn, wm, wn, prec, tf)

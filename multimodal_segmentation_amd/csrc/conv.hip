@@ -132,7 +132,10 @@ __device__ __forceinline__ f32x4 gather_a(const ConvParams& p, int b, int hb, in
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+// PREC != 0 (reduced-precision modes, forward launches with 4-channel gathers): the fp32 LDS tiles are unchanged, the operands are
+// rounded to the 16-bit type as they are read and multiplied on v_mfma_f32_32x32x16_* -- a 32-deep K tile is 2 MFMAs of 32 cycles
+// per output tile instead of 16 of 64, which is what the small-K layers of the SPADE units (8 -> 128, K = 72) are bound by in fp32
+template <int BM, int BN, int WM, int WN, bool VEC, int PREC = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -235,6 +238,30 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvParams p) {
     const int b_col = wn * (BN / WN) + li;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) load_tile(kt + 1);   // global loads stay in flight under the MFMAs
+        if constexpr (PREC != 0) {
+            typedef typename LowPrec<PREC>::T LT;
+            typedef typename LowPrec<PREC>::V8 LV8;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {      // two k-steps of 16; lane half lh supplies k = 16 q + 8 lh + [0, 8)
+                const int kb = 16 * q + 8 * lh;
+                LV8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(&As[(a_row + i * 32) * AS_LD + kb]);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(&As[(a_row + i * 32) * AS_LD + kb + 4]);
+                    a[i] = LV8{(LT)lo[0], (LT)lo[1], (LT)lo[2], (LT)lo[3], (LT)hi[0], (LT)hi[1], (LT)hi[2], (LT)hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b[j][e] = (LT)Bs[(kb + e) * BS_LD + b_col + j * 32];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = LowPrec<PREC>::mfma(a[i], b[j], acc[i][j]);
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 a[TM];
@@ -705,6 +732,14 @@ static int launch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
     MMSEG_SET_LAST(2, BM, BN);
     if (vec) g_last_kernel += 500000;                   // the 16-byte-gather instantiation
     dim3 grid(ntm * ntn), block(WM * WN * 64);
+    // reduced-precision modes: forward launches with 4-channel gathers multiply 16-bit operands (MMSEG_GENERIC_LP=0: fp32, for A/B runs)
+    static const bool lp_on = [] { const char* e = getenv("MMSEG_GENERIC_LP"); return !(e && e[0] == '0'); }();
+    if (vec && !p.transposed && g_conv_bf16 != 0 && lp_on) {
+        g_last_kernel += 250000;
+        if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, 1>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, 2>), grid, block, 0, st, p);
+        return MMSEG_CHECK_LAUNCH();
+    }
     if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), grid, block, 0, st, p);
     return MMSEG_CHECK_LAUNCH();

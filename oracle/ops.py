@@ -26,7 +26,7 @@ _OPERAND_ROUNDING = [None]
 def set_conv_operand_rounding(dtype):
     """None (default) | torch.bfloat16 | torch.float16: emulate the product's reduced-precision compute modes (BASELINE
     configs #3 / #5; NOT a reference behaviour -- the reference is fp32 throughout).  In those modes the product's MFMA
-    convolutions (input channels a multiple of 32, output channels a multiple of 4) multiply operands ROUNDED to the 16-bit
+    convolutions (input channels a multiple of 4) multiply operands ROUNDED to the 16-bit
     type and accumulate in fp32; every other operation stays fp32.  With the rounding emulated here the products are exact in
     both implementations and only the accumulation order differs.  Returns the previous setting."""
     old = _OPERAND_ROUNDING[0]
@@ -52,7 +52,10 @@ def conv2d(x, w, b=None, stride=1, padding='same'):
         pad = (kh // 2, kw // 2)
     else:
         pad = (0, 0)
-    if _OPERAND_ROUNDING[0] is not None and w.shape[2] % 32 == 0 and w.shape[3] % 4 == 0:
+    # MFMA kernels of the product in those modes: every forward convolution whose input channel count is a multiple of 4,
+    # except the 8 -> 8 3x3 'same' layers of the FiLM decoder (a direct fp32 FMA kernel)
+    direct8 = (kh == 3 and kw == 3 and w.shape[2] == 8 and w.shape[3] == 8 and stride == 1 and padding == 'same')
+    if _OPERAND_ROUNDING[0] is not None and w.shape[2] % 4 == 0 and not direct8:
         x, w = _round_operand(x), _round_operand(w)
     y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, stride=stride, padding=pad)
     return y.permute(0, 2, 3, 1)

@@ -433,9 +433,9 @@ def test_conv2d_bf16_precision(B, H, W, Cin, C2, Cout, k, stride, padding, ups, 
     finally:
         P.set_conv_precision(prev)
     _close(y, yr, 'bf16 forward')
-    # data gradient: the kernel rounds the incoming gradient and the weights -- on the fast path (Cout % 32 == 0); the
-    # generic kernel that serves the other shapes is fp32 only
-    r_ = _bf16 if Cout % 32 == 0 else (lambda t: t.double())
+    # data gradient: the kernel rounds the incoming gradient and the weights -- on the fast path (Cout % 32 == 0) and in the
+    # 16-bit variant of the generic kernel (stride-1 launches with 4-channel gathers: Cout % 4 == 0); other shapes are fp32 only
+    r_ = _bf16 if (Cout % 32 == 0 or (Cout % 4 == 0 and stride == 1)) else (lambda t: t.double())
     gx = torch.autograd.grad(O.conv2d(xin, r_(wr.detach()), None, stride=stride, padding=padding), [xr1] + ([xr2] if C2 else []),
                              r_(cot))
     _close(xp1.grad, gx[0], 'bf16 dgrad x1', 4e-4)
