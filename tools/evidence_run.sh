@@ -1,8 +1,8 @@
 # One GPU-box session that regenerates the evidence kept under profiles/ (bench lines, kernel traces, GPU-busy with / without hipGraphs,
-# PMC passes):   gpurun -- "bash tools/evidence_run.sh"; summaries are then made from gpurun_out/ev3 with the tools/*.py scripts
+# PMC passes):   gpurun -- "bash tools/evidence_run.sh"; summaries are then made from gpurun_out/ev4 with the tools/*.py scripts
 # (DESIGN.md section 6).  Every profiled program stands directly after `--`; --pmc passes carry no other trace domain.
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ev3; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ev4; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 3 > $O/bench_f32.json 2> $O/bench_f32.err
 echo bench done
@@ -17,19 +17,19 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_bf16a -o p -- pyt
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_bf16a -o p -- python3 $R/bench.py --no-cpu-baseline --no-conv-timer --dtype bf16 --act16 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_write_bf16a.err
 echo pmc traffic done
 for shape in "fwd 128 128 128" "fwd 256 64 64"; do set -- $shape; n=$1_$2_$3_$4
-  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma_$n -o p -- python3 $R/tools/conv_one.py $2 $3 $4 fwd > /dev/null 2>&1
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$n -o p -- python3 $R/tools/conv_one.py $2 $3 $4 fwd > /dev/null 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_lds_$n -o p -- python3 $R/tools/conv_one.py $2 $3 $4 fwd > /dev/null 2>&1
 done
 for shape in "128 128 0 128 0" "256 64 0 64 0"; do set -- $shape; n=wgrad_$1_$2_$4
-  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma_$n -o p -- python3 $R/tools/wgrad_one.py $1 $2 $3 $4 $5 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$n -o p -- python3 $R/tools/wgrad_one.py $1 $2 $3 $4 $5 > /dev/null 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_lds_$n -o p -- python3 $R/tools/wgrad_one.py $1 $2 $3 $4 $5 > /dev/null 2>&1
 done
 echo pmc fp32 kernels done
 export DTYPE=bf16
 for io in 0 5; do export IO=$io
-  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/pmc16_mfma_fwd_io$io -o p -- python3 $R/tools/conv_one.py 128 128 128 fwd > /dev/null 2>&1
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc16_mfma_fwd_io$io -o p -- python3 $R/tools/conv_one.py 128 128 128 fwd > /dev/null 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $O/pmc16_lds_fwd_io$io -o p -- python3 $R/tools/conv_one.py 128 128 128 fwd > /dev/null 2>&1
-  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/pmc16_mfma_wgrad_io$io -o p -- python3 $R/tools/wgrad_one.py 128 128 0 128 0 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc16_mfma_wgrad_io$io -o p -- python3 $R/tools/wgrad_one.py 128 128 0 128 0 > /dev/null 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $O/pmc16_lds_wgrad_io$io -o p -- python3 $R/tools/wgrad_one.py 128 128 0 128 0 > /dev/null 2>&1
 done
 unset DTYPE IO

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Turn the raw output of tools/evidence_run.sh (gpurun_out/ev3) into the summaries tracked under profiles/ (round 2):
+"""Turn the raw output of tools/evidence_run.sh (gpurun_out/ev4) into the summaries tracked under profiles/ (round 2):
 
-    python tools/evidence_to_profiles.py [gpurun_out/ev3]
+    python tools/evidence_to_profiles.py [gpurun_out/ev4]
 
   r02_bench_lines.jsonl                         every bench.py JSON line of the session, labelled
   r02_final_kernel_stats_<workload>.{txt,csv}    per-kernel table of the rocprofv3 kernel trace of `python3 bench.py` (headline workload)
@@ -20,7 +20,7 @@ from contextlib import redirect_stdout
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
-EV = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'ev3')
+EV = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'ev4')
 P = os.path.join(ROOT, 'profiles')
 W = 'bench_dafnet_film_256_bs8'
 
