@@ -8,13 +8,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _build(hip_graphs, decoder='film'):
+def _build(hip_graphs, decoder='film', **extra):
     from multimodal_segmentation_amd import nn
     from multimodal_segmentation_amd.configuration import dafnet_config_chaos
     from multimodal_segmentation_amd.models.dafnet import DAFNet
     from tests import helpers as Hh
     nn.set_default_device('cuda:0')
-    conf = Hh.make_conf(dafnet_config_chaos, 64, hip_graphs=hip_graphs, decoder_type=decoder)
+    conf = Hh.make_conf(dafnet_config_chaos, 64, hip_graphs=hip_graphs, decoder_type=decoder, **extra)
     model = DAFNet(conf)
     model.build()
     return model
@@ -24,7 +24,9 @@ def _state(models):
     return [w.copy() for m in models for w in m.get_weights()]
 
 
-def test_discriminator_and_generator_steps_replayed_from_graphs_are_bitwise_the_eager_steps():
+@pytest.mark.parametrize('extra', [{}, {'compute_dtype': 'bf16', 'act_storage': 'half'}], ids=['fp32', 'bf16-act16'])
+def test_discriminator_and_generator_steps_replayed_from_graphs_are_bitwise_the_eager_steps(extra):
+    from multimodal_segmentation_amd import ops as P
     from tests import helpers as Hh
     B, H, steps = 2, 64, 5
     rng = np.random.RandomState(3)
@@ -33,7 +35,7 @@ def test_discriminator_and_generator_steps_replayed_from_graphs_are_bitwise_the_
     runs = {}
     ref_w = None
     for mode in (False, True):
-        model = _build(mode)
+        model = _build(mode, **extra)
         ms = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
         if ref_w is None:
             ref_w = [m.get_weights() for m in ms]
@@ -58,6 +60,8 @@ def test_discriminator_and_generator_steps_replayed_from_graphs_are_bitwise_the_
             assert len(g) == 1 and list(g.values())[0].graph is not None, 'the generator step was not recorded'
             assert len(list(g.values())[0].draws) >= 2, 'the host draws of the sampling layer were not listed'
         runs[mode] = (losses, _state(ms), model.supervised_trainer.optimizer.iterations)
+    P.set_activation_storage(False)
+    P.set_conv_precision('fp32')
     (l0, w0, it0), (l1, w1, it1) = runs[False], runs[True]
     assert it0 == it1 == steps
     for (k0, v0), (k1, v1) in zip(l0, l1):
