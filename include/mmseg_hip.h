@@ -195,6 +195,10 @@ int mmseg_upsample2_bwd_t(const void* dy, void* dx, int B, int H, int W, int C, 
  * mmseg_colsum_workspace_floats(M, C) floats) -- one pass instead of mmseg_act_bwd + mmseg_colsum */
 int mmseg_act_bwd_bias_t(const void* dy, const void* y, void* dx, float* bias_grad, float* ws, long M, int C, int act, float alpha,
                          int accumulate, int h, void* stream);
+/* out[B*H*W][96] (16-bit, code hy) = im2col of x[B,H,W,8] (code hx) for a 3x3 stride-1 'same' convolution: K index = tap * 8 + channel,
+ * columns 72..95 zero.  A 1x1 fast-path convolution over it (Cin = 96, weights = the Keras kernel read as [72][Cout] + 24 zero rows)
+ * is the reduced-precision form of the SPADE units' 8 -> 128 convolution (layers/spade.py:28) */
+int mmseg_im2col8_t(const void* x, void* out, int B, int H, int W, int hx, int hy, void* stream);
 /* keras_contrib InstanceNormalization(axis=None) fused with SPADE_COND and LeakyReLU (layers/spade.py:7-33,51-54) */
 int mmseg_in_workspace_floats(int B);
 int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, float* ws, int B,

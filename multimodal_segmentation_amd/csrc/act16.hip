@@ -307,6 +307,34 @@ __global__ void act16_bwd_flat_kernel(const void* __restrict__ dy, const void* _
     }
 }
 
+
+// ---- im2col of an 8-channel tensor for a 3x3 'same' convolution ------------------------------------------------------------------
+// out[p][tap * 8 + c] = x[p + delta(tap)][c] (zero outside the image), taps 9..11 zero: rows of 96 elements of the 16-bit operand
+// type, i.e. the input of a 1x1 fast-path convolution with K = 96 (three 32-wide K tiles).  The SPADE units' shared convolution
+// (8 -> 128, K = 72: layers/spade.py:28) then runs on the 16-bit MFMA fast path instead of the generic per-lane gather.  One
+// thread per (pixel, tap): a 32-byte (fp32 source) or 16-byte load, one 16-byte store; consecutive threads write consecutive chunks.
+template <int HX, int HY>
+__global__ __launch_bounds__(256) void im2col8_kernel(const void* __restrict__ x, void* __restrict__ out, int B, int H, int W) {
+    const long n = (long)B * H * W * 12;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 12);
+        const long p = i / 12;
+        const int wq = (int)(p % W);
+        const long r = p / W;
+        const int hq = (int)(r % H);
+        const long b = r / H;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int hi = hq + kh - 1, wi = wq + kw - 1;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi4 = lo;
+        if (tap < 9 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+            const long src = ((b * H + hi) * W + wi) * 2;      // in units of 4 elements
+            lo = ld4<HX>(x, src); hi4 = ld4<HX>(x, src + 1);
+        }
+        st4<HY>(out, i * 2, lo);
+        st4<HY>(out, i * 2 + 1, hi4);
+    }
+}
+
 static inline bool hcode_ok(int h) { return h >= 0 && h <= 2; }
 // (hx, hy) pairs that occur: a tensor is fp32 or THE 16-bit type of the run
 #define DISPATCH_HH(hx, hy, LAUNCH)                                              \
@@ -419,6 +447,19 @@ int mmseg_act_bwd_bias_t(const void* dy, const void* y, void* dx, float* bias_gr
     DISPATCH_H(h, L);
 #undef L
     hipLaunchKernelGGL(colsum16_final_kernel, dim3(C), dim3(256), 0, st, (const float*)ws, bias_grad, (int)nb, C, accumulate);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+
+// out[B*H*W][96] (element code hy: 1 bf16 / 2 fp16) = im2col of x[B,H,W,8] (element code hx) for a 3x3 stride-1 'same' convolution,
+// K index = tap * 8 + channel, columns 72..95 zero -- see im2col8_kernel
+int mmseg_im2col8_t(const void* x, void* out, int B, int H, int W, int hx, int hy, void* stream) {
+    if (!hcode_ok(hx) || (hy != 1 && hy != 2) || B <= 0 || H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+    if (hx != 0 && hx != hy) return (int)hipErrorInvalidValue;
+    const long n = (long)B * H * W * 12;
+#define L(HX, HY) hipLaunchKernelGGL((im2col8_kernel<HX, HY>), dim3(grid16(n)), dim3(256), 0, (hipStream_t)stream, x, out, B, H, W)
+    DISPATCH_HH(hx, hy, L);
+#undef L
     return MMSEG_CHECK_LAUNCH();
 }
 

@@ -49,6 +49,7 @@ struct ConvParams {
     // 16-bit tensors in HBM (reduced-precision modes only; the `_t` entry points): bit 0 = x1, bit 1 = x2, bit 2 = y / y2 are stored in
     // the 16-bit type of the active precision mode, bit 3 = that type is fp16 (else bf16).  0 = all fp32.
     int io;
+    int qepi;       // fast path: the epilogue may use the quad-transposed vector stores (set by the host: alignment, MMSEG_QUAD_EPI)
 };
 
 #define BK 32
@@ -334,6 +335,10 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int byte_of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
+// vector stores of the quad-transposed epilogue need 16-byte (fp32) / 8-byte (16-bit) aligned rows: the host checks the
+// base pointers (ConvParams::qepi)
+__device__ __forceinline__ bool quad_epilogue_enabled(const ConvParams& p) { return p.qepi != 0; }
+
 template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false, int KT = BK>
 __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bid, const int nblk) {
     constexpr int NT = WM * WN * 64;
@@ -617,6 +622,63 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[0][i][j] += acc[s][i][j];
 
+    // ---- epilogue.  The accumulator layout gives a lane ONE output channel (column li) of 16 rows: stored as it is, every store
+    // instruction moves one element per lane.  Where the channel count allows, each group of 4 rows x 4 lanes (a quad = 4
+    // adjacent channels) is transposed inside the quad with two DPP exchanges, after which a lane owns 4 CONSECUTIVE channels of
+    // one row: one 16-byte (fp32) or 8-byte (16-bit) store instead of four -- 4 store instructions per 32 x 32 tile instead of
+    // 16, same 128-byte segments.  The 16-bit convolutions with few K tiles were bound by exactly those stores.
+    if (p.Cout % 4 == 0 && (p.y2 == nullptr || p.nsplit1 % 4 == 0) && quad_epilogue_enabled(p)) {
+        const int tq = lane & 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + li;
+            const bool nok = n < p.Cout;                 // uniform inside a quad (Cout % 4 == 0)
+            const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+            const float sv = (nok && p.oscale) ? p.oscale[n] : 1.f;
+            const int nq = n - tq;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = act_apply(acc[0][i][j][4 * g + e] * sv + bv, p.act, p.alpha);
+                    // 4 x 4 transpose inside the quad: exchange with lane ^ 1 on register pairs (0,1),(2,3), then with lane ^ 2 on (0,2),(1,3)
+#pragma unroll
+                    for (int pp = 0; pp < 4; pp += 2) {
+                        const float send = (tq & 1) ? a[pp] : a[pp + 1];
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+                        if (tq & 1) a[pp] = recv; else a[pp + 1] = recv;
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const float send = (tq & 2) ? a[pp] : a[pp + 2];
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));
+                        if (tq & 2) a[pp] = recv; else a[pp + 2] = recv;
+                    }
+                    // this lane now holds channels nq .. nq + 3 of row (8 g + 4 lh + tq) of the tile
+                    int m = row_to_m(wm * (BM / WM) + i * 32 + 8 * g + 4 * lh + tq);
+                    if (!nok || m >= p.M) continue;
+                    if (omap) {
+                        const int ob = m / HoWo, orr = m - ob * HoWo;
+                        const int oh = orr / p.Wo, ow = orr - oh * p.Wo;
+                        m = (ob * p.oH + oh * p.osh + p.ooh) * p.oW + ow * p.osw + p.oow;
+                    }
+                    const bool first = p.y2 == nullptr || nq < p.nsplit1;
+                    const size_t o = p.y2 == nullptr ? (size_t)m * p.Cout + nq
+                                     : (first ? (size_t)m * p.nsplit1 + nq : (size_t)m * (p.Cout - p.nsplit1) + (nq - p.nsplit1));
+                    if (BF16 && (p.io & 4)) {
+                        LT* base = reinterpret_cast<LT*>(first ? (void*)p.y : (void*)p.y2);
+                        *reinterpret_cast<LV4*>(base + o) = LV4{(LT)a[0], (LT)a[1], (LT)a[2], (LT)a[3]};
+                    } else {
+                        float* base = first ? p.y : p.y2;
+                        *reinterpret_cast<f32x4*>(base + o) = f32x4{a[0], a[1], a[2], a[3]};
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 32 + li;
@@ -799,8 +861,16 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// the quad-transposed epilogue stores 4 channels per lane: 16-byte (fp32) / 8-byte (16-bit) aligned output rows
+static int quad_epilogue_ok(const ConvParams& p) {
+    static const bool on = [] { const char* e = getenv("MMSEG_QUAD_EPI"); return !(e && e[0] == '0'); }();
+    const uintptr_t al = (p.io & 4) ? 7 : 15;
+    return (on && (reinterpret_cast<uintptr_t>(p.y) & al) == 0 && (p.y2 == nullptr || (reinterpret_cast<uintptr_t>(p.y2) & al) == 0)) ? 1 : 0;
+}
+
 static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (p.M <= 0 || p.Cout <= 0 || p.K <= 0) return (int)hipErrorInvalidValue;
+    p.qepi = quad_epilogue_ok(p);
     if (p.C1 == 8 && p.C2 == 0 && p.Cout == 8 && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.transposed && !p.ups &&
         p.Ho == p.H && p.Wo == p.W && p.pad_h == 1 && p.pad_w == 1 && p.y2 == nullptr && p.w != nullptr && p.osh == 1 &&
         p.oscale == nullptr && aligned16(p.x1) && aligned16(p.y) && (long)p.M * 8 * 4 < (1L << 31) - 64 && p.io == 0) {
@@ -1913,6 +1983,7 @@ int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* d
                 p.Ho = Hs; p.Wo = Ws; p.Cout = Cin; p.KH = TH; p.KW = TW; p.stride = 1;
                 p.pad_h = TH - 1; p.pad_w = TW - 1; p.ups = 0; p.transposed = 0; p.act = 0; p.alpha = 0.f;
                 p.M = B * Hs * Ws; p.K = TH * TW * Cout; p.nsplit1 = 0; p.io = 0;
+                p.qepi = quad_epilogue_ok(p);
                 if (p.M > maxM) maxM = p.M;
                 if (((uintptr_t)p.wt & 15) != 0) return (int)hipErrorInvalidValue;
             }

@@ -126,6 +126,25 @@ def _wprep(w, KH, KW, Cin, Cout, mode, wkey=None):
     return out
 
 
+def _wprep_col8(w, Cout, wkey=None):
+    """fast-path weight image of a 3x3 kernel with 8 input channels read as a 1x1 kernel over the 96-column im2col rows of
+    mmseg_im2col8_t: [72][Cout] + 24 zero rows -> [Cout][96]; cached per weight version like _wprep"""
+    key = (wkey, w.data_ptr(), 'col8')
+    ent = _wprep_cache.get(key) if wkey is not None else None
+    if ent is not None and ent[0] == _weight_version[0]:
+        return ent[1]
+    if ent is not None:
+        pad, out = ent[2], ent[1]
+    else:
+        pad = torch.zeros(96 * Cout, dtype=torch.float32, device=w.device)
+        out = torch.empty(96 * Cout, dtype=torch.float32, device=w.device)
+    pad[:72 * Cout].copy_(w.reshape(-1))
+    N.call('mmseg_conv2d_wprep', pad, out, 1, 1, 96, Cout, 0)
+    if wkey is not None:
+        _wprep_cache[key] = (_weight_version[0], out, pad)
+    return out
+
+
 def _wprep_parity_all(w, KH, KW, Cin, Cout, stride, taps, wkey=None):
     """The sub-kernels of all stride x stride parity classes back to back in (ph, pw) raster order (the operand of
     mmseg_conv2d_dgrad_parity_all); cached per weight version like _wprep."""
@@ -206,9 +225,21 @@ class _Conv2d(torch.autograd.Function):
         assert Cin == C1 + C2, 'kernel expects %d input channels, got %d' % (Cin, C1 + C2)
         Ho, Wo, ph, pw = _conv_geometry(H, W, KH, KW, stride, padding)
         y = _new((B, Ho, Wo, Cout), x1, out_dtype)
-        wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
-        _conv_fwd_raw(x1, x2, w, wt, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,
-                      ACT[act], alpha, 0)
+        prec = N.call('mmseg_get_conv_precision')
+        if prec and C1 == 8 and C2 == 0 and KH == 3 and KW == 3 and stride == 1 and not ups and (Ho, Wo, ph, pw) == (H, W, 1, 1) \
+                and Cout % 64 == 0 and _h(x1) in (0, prec):
+            # reduced-precision modes, 8 input channels (the SPADE units' shared convolution, the segmentor's first): K = 72 is three
+            # gathers of the generic kernel per output tile; instead the 72 (+24 zero) operand columns of every pixel are written
+            # once as 16-bit rows and the product runs as a 1x1 convolution on the 16-bit MFMA fast path
+            half = torch.bfloat16 if prec == 1 else torch.float16
+            xcol = torch.empty((B, H, W, 96), dtype=half, device=x1.device)
+            N.call('mmseg_im2col8_t', x1, xcol, B, H, W, _h(x1), prec)
+            _conv_fwd_raw(xcol, None, None, _wprep_col8(w, Cout, wkey), bias, y, None, B, H, W, 96, 0, Ho, Wo, Cout, 1, 1, 1, 0, 0, 0, 0,
+                          ACT[act], alpha, 0)
+        else:
+            wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
+            _conv_fwd_raw(x1, x2, w, wt, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,
+                          ACT[act], alpha, 0)
         ctx.geom = (B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), ACT[act], alpha)
         ctx.wgrad, ctx.bgrad, ctx.wkey = wgrad, bgrad, wkey
         ctx.w = w     # plain (non-leaf) weight view: not tracked by autograd
