@@ -70,6 +70,32 @@ template <> struct LowPrec<2> {
 template <> struct LowPrec<0> { typedef float T; typedef f32x4 V4; typedef f32x4 V8; };   // unused placeholder
 #define AS_LD (BK + 4)
 
+// 4 x 4 transpose inside a quad of lanes (tq = lane & 3): a[k] of lane t becomes a[t] of lane k.  Two DPP exchanges: with lane ^ 1 on
+// the register pairs (0,1),(2,3), then with lane ^ 2 on (0,2),(1,3).  Used by the epilogues: the MFMA accumulator layout gives a lane
+// one output channel of 4 consecutive rows; transposed, the lane owns 4 consecutive channels of one row = one vector store.
+__device__ __forceinline__ void quad_transpose4(float (&a)[4], const int tq) {
+#pragma unroll
+    for (int pp = 0; pp < 4; pp += 2) {
+        const float send = (tq & 1) ? a[pp] : a[pp + 1];
+        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+        if (tq & 1) a[pp] = recv; else a[pp + 1] = recv;
+    }
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const float send = (tq & 2) ? a[pp] : a[pp + 2];
+        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));
+        if (tq & 2) a[pp] = recv; else a[pp + 2] = recv;
+    }
+}
+// 4 consecutive output channels of one pixel row, as fp32 or as the 16-bit type selected by ConvParams::io (bit 2: 16-bit, bit 3: fp16)
+__device__ __forceinline__ void store4_out(void* base, size_t o, const float (&a)[4], int io) {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    if (!(io & 4)) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + o) = f32x4{a[0], a[1], a[2], a[3]};
+    else if (io & 8) *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(base) + o) = h4{(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3]};
+    else *reinterpret_cast<b4*>(reinterpret_cast<__bf16*>(base) + o) = b4{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+}
+
 __device__ __forceinline__ f32x4 gather_tap4(const ConvParams& p, int b, int hb, int wb, int kh, int kw, int c) {
     // returns 4 consecutive channels c..c+3 of the (possibly virtual) input at the tap, or zeros
     int hi = hb + kh, wi = wb + kw;
@@ -289,6 +315,34 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fwd_kernel(ConvParams p) {
     }
 
     // ---- epilogue: bias + activation, rows of 32 consecutive channels per half-wave ---------
+    if (p.qepi && p.Cout % 4 == 0 && (p.y2 == nullptr || p.nsplit1 % 4 == 0)) {      // quad-transposed vector stores (see conv_fast_body)
+        const int tq = lane & 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + li;
+            const bool nok = n < p.Cout;
+            const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+            const float sv = (nok && p.oscale) ? p.oscale[n] : 1.f;
+            const int nq = n - tq;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = act_apply(acc[i][j][4 * g + e] * sv + bv, p.act, p.alpha);
+                    quad_transpose4(a, tq);
+                    const int m = m0 + wm * (BM / WM) + i * 32 + 8 * g + 4 * lh + tq;
+                    if (!nok || m >= p.M) continue;
+                    const bool first = p.y2 == nullptr || nq < p.nsplit1;
+                    const size_t o = p.y2 == nullptr ? (size_t)m * p.Cout + nq
+                                     : (first ? (size_t)m * p.nsplit1 + nq : (size_t)m * (p.Cout - p.nsplit1) + (nq - p.nsplit1));
+                    store4_out(first ? (void*)p.y : (void*)p.y2, o, a, p.io);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 32 + li;
@@ -643,19 +697,7 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
                     float a[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] = act_apply(acc[0][i][j][4 * g + e] * sv + bv, p.act, p.alpha);
-                    // 4 x 4 transpose inside the quad: exchange with lane ^ 1 on register pairs (0,1),(2,3), then with lane ^ 2 on (0,2),(1,3)
-#pragma unroll
-                    for (int pp = 0; pp < 4; pp += 2) {
-                        const float send = (tq & 1) ? a[pp] : a[pp + 1];
-                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
-                        if (tq & 1) a[pp] = recv; else a[pp + 1] = recv;
-                    }
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
-                        const float send = (tq & 2) ? a[pp] : a[pp + 2];
-                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));
-                        if (tq & 2) a[pp] = recv; else a[pp + 2] = recv;
-                    }
+                    quad_transpose4(a, tq);
                     // this lane now holds channels nq .. nq + 3 of row (8 g + 4 lh + tq) of the tile
                     int m = row_to_m(wm * (BM / WM) + i * 32 + 8 * g + 4 * lh + tq);
                     if (!nok || m >= p.M) continue;
@@ -667,13 +709,7 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
                     const bool first = p.y2 == nullptr || nq < p.nsplit1;
                     const size_t o = p.y2 == nullptr ? (size_t)m * p.Cout + nq
                                      : (first ? (size_t)m * p.nsplit1 + nq : (size_t)m * (p.Cout - p.nsplit1) + (nq - p.nsplit1));
-                    if (BF16 && (p.io & 4)) {
-                        LT* base = reinterpret_cast<LT*>(first ? (void*)p.y : (void*)p.y2);
-                        *reinterpret_cast<LV4*>(base + o) = LV4{(LT)a[0], (LT)a[1], (LT)a[2], (LT)a[3]};
-                    } else {
-                        float* base = first ? p.y : p.y2;
-                        *reinterpret_cast<f32x4*>(base + o) = f32x4{a[0], a[1], a[2], a[3]};
-                    }
+                    store4_out(first ? (void*)p.y : (void*)p.y2, o, a, BF16 ? p.io : 0);
                 }
             }
         }
