@@ -476,15 +476,20 @@ __device__ __forceinline__ void conv_fast_body(const ConvParams& p, const int bi
         const int m = (BM % A_RPA == 0 || row < BM) ? row_to_m(row) : p.M;
         a_msk[j] = 0u;
         if (m < p.M) {
-            const int b = m / HoWo, r = m - b * HoWo;
-            const int ho = r / p.Wo, wo = r - ho * p.Wo;
+            // (b, ho, wo) of the row: known without divisions for the 2-D pixel tiles
+            int b, ho, wo;
+            if (tile2d) { b = t_b; ho = t_y0 + (row >> 4); wo = t_x0 + (row & 15); }
+            else { b = m / HoWo; const int r = m - b * HoWo; ho = r / p.Wo; wo = r - ho * p.Wo; }
             const int hb = ho * p.stride - p.pad_h, wb = wo * p.stride - p.pad_w;
             a_hb[j] = hb; a_wb[j] = wb;
             a_o1[j] = p.ups ? b * p.H1 : (((b * p.H + hb) * p.W + wb) * p.C1 + ecA) * ES;
             a_o2[j] = (((b * p.H + hb) * p.W + wb) * p.C2 + ecA) * ES;
+            // validity mask = (rows kh inside the image) x (columns kw inside): KH + KW tests instead of KH * KW
+            unsigned wm_ = 0u;
+            for (int kw = 0; kw < p.KW; ++kw)
+                if ((unsigned)(wb + kw) < (unsigned)p.W) wm_ |= 1u << kw;
             for (int kh = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw)
-                    if ((unsigned)(hb + kh) < (unsigned)p.H && (unsigned)(wb + kw) < (unsigned)p.W) a_msk[j] |= 1u << (kh * p.KW + kw);
+                if ((unsigned)(hb + kh) < (unsigned)p.H) a_msk[j] |= wm_ << (kh * p.KW);
         } else {
             a_hb[j] = 0; a_wb[j] = 0; a_o1[j] = 0; a_o2[j] = 0;
         }
