@@ -227,7 +227,7 @@ class _Conv2d(torch.autograd.Function):
         y = _new((B, Ho, Wo, Cout), x1, out_dtype)
         prec = N.call('mmseg_get_conv_precision')
         if prec and C1 == 8 and C2 == 0 and KH == 3 and KW == 3 and stride == 1 and not ups and (Ho, Wo, ph, pw) == (H, W, 1, 1) \
-                and Cout % 64 == 0 and _h(x1) in (0, prec):
+                and Cout % 64 == 0 and _h(x1) in (0, prec) and B * H * W * 96 * 2 < (1 << 31) - 64:
             # reduced-precision modes, 8 input channels (the SPADE units' shared convolution, the segmentor's first): K = 72 is three
             # gathers of the generic kernel per output tile; instead the 72 (+24 zero) operand columns of every pixel are written
             # once as 16-bit rows and the product runs as a 1x1 convolution on the 16-bit MFMA fast path

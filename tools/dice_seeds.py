@@ -85,7 +85,8 @@ def summary(paths):
     n = len(diffs)
     mean = float(np.mean(diffs))
     sd = float(np.std(diffs, ddof=1)) if n > 1 else float('nan')
-    tcrit = {2: 12.71, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365}.get(n, 1.96)
+    tcrit = {2: 12.71, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365, 9: 2.306, 10: 2.262, 11: 2.228, 12: 2.201,
+             13: 2.179, 14: 2.160, 15: 2.145, 16: 2.131}.get(n, 1.96)     # Student t, 97.5 %, n - 1 degrees of freedom
     half = tcrit * sd / math.sqrt(n) if n > 1 else float('nan')
     print('n = %d seeds: Dice product %.4f +- %.4f (sd), oracle %.4f +- %.4f (sd)' % (n, np.mean(pm), np.std(pm, ddof=1) if n > 1 else 0,
                                                                                      np.mean(om), np.std(om, ddof=1) if n > 1 else 0))
