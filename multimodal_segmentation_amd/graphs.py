@@ -8,7 +8,8 @@ recorded into a graph (torch.cuda.CUDAGraph = hipGraph on ROCm; every kernel of 
 which during the recording is the capturing stream) and every later step replays it with one host call.  What varies from step to
 step lives in device memory the recorded kernels read:
 
-  * the inputs and tensor targets of the call  -> static buffers the replay copies into first;
+  * the inputs and tensor targets of the call  -> static buffers the replay copies into first (the executors' fake pools, pure
+    inference passes, are recorded the same way: `GraphedCall`);
   * values the step draws on the host (the noise of the sampling layer, `host_draw`) -> static buffers refilled from the same host
     generators in the same order, so a replayed run consumes exactly the random streams of an eager run;
   * Adam's bias-corrected step size lr_t        -> one device float (`mmseg_adam_p`), written before the replay.
@@ -44,6 +45,59 @@ def host_draw(fn, device):
     d = st.draws[st.draw_i]
     st.draw_i += 1
     return d.buf
+
+
+class GraphedCall(object):
+    """A no-grad device function of tensors -> tuple of tensors (the executors' fake pools: inference passes of the generator's
+    components on a fresh batch) recorded per input-shape signature after WARMUP eager calls.  The returned tensors are the
+    graph's static outputs: valid until the next call of the same signature (the pools are sampled right away).  Host draws inside
+    (the sampling layer's noise) go through `host_draw` as in a trainer step."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.states = {}
+
+    def __call__(self, *xs):
+        global _recording
+        from . import ops
+        from .parallel import dp
+        if dp.enabled() or not all(isinstance(x, torch.Tensor) and x.is_cuda for x in xs):
+            return self.fn(*xs)
+        key = tuple((tuple(x.shape), x.dtype) for x in xs)
+        st = self.states.get(key)
+        if st is None:
+            st = self.states[key] = FitGraph(None)
+        st.calls += 1
+        if st.calls <= WARMUP:
+            if st.calls == WARMUP:
+                st.mode, st.draws = 'discover', []
+                _recording = st
+                try:
+                    return self.fn(*xs)
+                finally:
+                    _recording = None
+            return self.fn(*xs)
+        if st.graph is None:
+            st.s_in = [torch.empty_like(x) for x in xs]
+        for b, x in zip(st.s_in, xs):
+            b.copy_(x)
+        for d in st.draws:
+            d.buf.copy_(torch.from_numpy(np.ascontiguousarray(d.fn(), np.float32)))
+        if st.graph is None:
+            ops.bump_weight_version()                 # every cached weight image / BatchNorm fold is recomputed INSIDE the recording
+            st.mode, st.draw_i = 'capture', 0
+            _recording = st
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g), torch.no_grad():
+                    st.outs = self.fn(*st.s_in)
+            finally:
+                _recording = None
+            assert st.draw_i == len(st.draws)
+            st.graph = g
+        st.graph.replay()
+        ops.bump_weight_version()                     # the images the replay wrote are not tagged with a host-side version
+        return st.outs
 
 
 def _sig(x):
@@ -113,6 +167,8 @@ class FitGraph(object):
             d.buf.copy_(torch.from_numpy(np.ascontiguousarray(d.fn(), np.float32)))
         lr_dev = t.optimizer.begin_device_step(dev)   # iteration count + 1, lr_t of this step into the device scalar
         if self.graph is None:
+            from . import ops as _ops
+            _ops.bump_weight_version()               # every cached weight image is recomputed INSIDE the recording
             self.mode, self.draw_i = 'capture', 0
             _recording = self
             g = torch.cuda.CUDAGraph()

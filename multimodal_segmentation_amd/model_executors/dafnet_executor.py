@@ -42,6 +42,11 @@ class DAFNetExecutor(Executor):
         self.ul_data = None
         self.device = model.D_Mask.device
         self.keep_losses_on_device = False
+        if bool(conf.get('hip_graphs', False)) and self.device.type == 'cuda':
+            # conf.hip_graphs: the fake pools (inference passes on a fresh batch) are recorded like the trainer steps (graphs.py)
+            from .. import graphs
+            self.mask_pools = graphs.GraphedCall(self.mask_pools)
+            self.image_pools = graphs.GraphedCall(self.image_pools)
         self.init_swa_models()
 
     # ---- Stochastic Weight Averaging plumbing (dafnet_executor.py:41-68) -------------------------------------------

@@ -68,3 +68,43 @@ def test_discriminator_and_generator_steps_replayed_from_graphs_are_bitwise_the_
         assert k0 == k1 and v0 == v1, 'loss %s: eager %r, graph %r' % (k0, v0, v1)
     for a, b in zip(w0, w1):
         assert np.array_equal(a, b)
+
+
+def test_executor_iterations_with_graphs_are_bitwise_the_eager_iterations():
+    """the whole DAFNetExecutor.train_batch with conf.hip_graphs (trainer steps AND the fake pools replayed from graphs): five
+    iterations end in bit-identical weights and per-iteration losses"""
+    from multimodal_segmentation_amd import nn
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    runs = {}
+    ref_w = None
+    for mode in (False, True):
+        np.random.seed(123)
+        conf = Hh.make_conf(dafnet_config_chaos, 64, batch_size=4, hip_graphs=mode)
+        model = DAFNet(conf)
+        model.build()
+        ms = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
+        if ref_w is None:
+            ref_w = [m.get_weights() for m in ms]
+        else:
+            for m, w in zip(ms, ref_w):
+                m.set_weights(w)
+        model.Enc_Modality._eps_rng = None
+        ex = DAFNetExecutor(conf, model)
+        np.random.seed(321)
+        ex.init_train_data(slices_per_volume=3)
+        losses = {n: [] for n in ex.get_loss_names()}
+        for _ in range(5):
+            ex.train_batch(losses)
+        if mode:
+            from multimodal_segmentation_amd import graphs
+            assert isinstance(ex.mask_pools, graphs.GraphedCall) and any(st.graph is not None for st in ex.mask_pools.states.values())
+            assert any(st.graph is not None for st in ex.image_pools.states.values())
+        runs[mode] = ({k: [float(v.item()) if hasattr(v, 'item') else float(v) for v in vs] for k, vs in losses.items()}, _state(ms))
+    (l0, w0), (l1, w1) = runs[False], runs[True]
+    assert l0 == l1, 'per-iteration losses differ between the eager and the graph-replayed executor'
+    for a, b in zip(w0, w1):
+        assert np.array_equal(a, b)
