@@ -52,6 +52,7 @@ def check(T, mode):
                     ad.append((16*(b+(((c&2)|lh)^f)),16))
                 worst_r=max(worst_r,conflicts(ad,64))
     return size, worst_w, worst_r
-for T in (32,64,128,192):
-    for mode in (32,16):
-        print(T, mode, check(T,mode))
+if __name__ == '__main__':
+    for T in (32,64,128,192):
+        for mode in (32,16):
+            print(T, mode, check(T,mode))
