@@ -272,6 +272,9 @@ def main():
                     help='with --dtype bf16 | f16: the activations / gradients of the MFMA trunk live in HBM in the 16-bit type (conf.act_storage = half)')
     ap.add_argument('--graphs', action='store_true',
                     help='conf.hip_graphs: every trainer step is recorded into a hipGraph after two eager steps and replayed (single GPU)')
+    ap.add_argument('--no-multi-stream', action='store_true',
+                    help='conf.multi_stream = False: the mask- and image-discriminator phases of an iteration one after the other on one '
+                         'stream (default: on concurrent HIP streams, bit-identical results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
     ap.add_argument('--conv-breakdown', action='store_true', help='per-shape convolution table on stderr')
@@ -330,6 +333,9 @@ def main():
             raise SystemExit('--act16 needs --dtype bf16 or f16')
         cfg['act_storage'] = 'half'
         DTYPE_NAME[args.dtype] = DTYPE_NAME[args.dtype].replace('(fp32 accumulate)', '(fp32 accumulate), 16-bit trunk activations in HBM')
+    cfg['multi_stream'] = not args.no_multi_stream
+    if not args.no_multi_stream:
+        DTYPE_NAME[args.dtype] += ', discriminator phases on concurrent streams'
     if args.graphs:
         cfg['hip_graphs'] = True
         args.no_conv_timer = True        # replayed launches do not pass through the Python call the timer hooks

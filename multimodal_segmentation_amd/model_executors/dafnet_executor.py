@@ -269,12 +269,33 @@ class DAFNetExecutor(Executor):
         auto = bool(self.conf.get('automatedpairing', False))
         if self.conf.l_mix > 0:
             (self.train_supervised_automated_pairing if auto else self.train_supervised_expert_pairing)(epoch_loss)
-            self.train_batch_mask_discriminator(epoch_loss)
-            self.train_batch_image_discriminator(epoch_loss)
+            self._train_discriminators(epoch_loss)
         if self.conf.l_mix < 1:
             (self.train_unsupervised_automated_pairing if auto else self.train_unsupervised_expert_pairing)(epoch_loss)
+            self._train_discriminators(epoch_loss)
+
+    def _train_discriminators(self, epoch_loss):
+        """mask-discriminator phase, then image-discriminator phase (dafnet_executor.py:378-386).  conf.multi_stream (build-defined,
+        default True; results are bit-identical either way): the two phases only READ the generator and update different discriminators, so they are queued on two
+        HIP streams (the second image discriminator on a third): the discriminators' small launches (a 27 x 27 plane is 92 tiles
+        for 256 CUs) then run beside the other phase's full-size inference convolutions instead of alone.  The host issues the
+        same launches in the same order (same random streams); scratch buffers and cached weight images are per stream (ops._sid).
+        Under data parallelism every rank queues the same collectives in the same order, each behind the launches of its own stream."""
+        # (not combined with conf.hip_graphs: replaying recorded steps from side streams did not reproduce the eager results)
+        if not (bool(self.conf.get('multi_stream', True)) and self.device.type == 'cuda' and not bool(self.conf.get('hip_graphs', False))):
             self.train_batch_mask_discriminator(epoch_loss)
             self.train_batch_image_discriminator(epoch_loss)
+            return
+        if getattr(self, '_streams', None) is None:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(3)]
+        sA, sB, sC = self._streams
+        main = torch.cuda.current_stream(self.device)
+        sA.wait_stream(main); sB.wait_stream(main)
+        with torch.cuda.stream(sA):
+            self.train_batch_mask_discriminator(epoch_loss)
+        with torch.cuda.stream(sB):
+            self.train_batch_image_discriminator(epoch_loss, second_stream=sC)
+        main.wait_stream(sA); main.wait_stream(sB)
 
     def _residual(self, m):
         """add_residual on whatever side the masks live (base_executor.py:83-87): background = 1 - union"""
@@ -401,14 +422,24 @@ class DAFNetExecutor(Executor):
         h = self.model.D_Mask_trainer.fit([m2, self._sample(pool2, mn)], [1.0, 0.0])
         epoch_loss['dis_M'].append(self._loss(h, 'loss'))
 
-    def train_batch_image_discriminator(self, epoch_loss):
-        """dafnet_executor.py:547-583"""
+    def train_batch_image_discriminator(self, epoch_loss, second_stream=None):
+        """dafnet_executor.py:547-583 (second_stream: the second image discriminator's step on its own stream, see _train_discriminators)"""
         x1, x2 = [_dev(next(gen), self.device) for gen in self.discriminator_image]
         mn = min(x1.shape[0], x2.shape[0])
         x1, x2 = x1[:mn], x2[:mn]
         y1, y2 = self.image_pools(x1, x2)
         y1 = self._sample(y1, mn)
         y2 = self._sample(y2, mn)
+        if second_stream is not None:
+            cur = torch.cuda.current_stream(self.device)
+            second_stream.wait_stream(cur)
+            with torch.cuda.stream(second_stream):
+                h2 = self.model.D_Image2_trainer.fit([x2, y2], [1.0, 0.0])
+            h = self.model.D_Image1_trainer.fit([x1, y1], [1.0, 0.0])
+            epoch_loss['dis_X1'].append(self._loss(h, 'loss'))
+            epoch_loss['dis_X2'].append(self._loss(h2, 'loss'))
+            cur.wait_stream(second_stream)
+            return
         h = self.model.D_Image1_trainer.fit([x1, y1], [1.0, 0.0])
         epoch_loss['dis_X1'].append(self._loss(h, 'loss'))
         h = self.model.D_Image2_trainer.fit([x2, y2], [1.0, 0.0])

@@ -18,10 +18,16 @@ IN_EPS = 1e-3        # keras_contrib InstanceNormalization default
 _workspaces = {}
 
 
+def _sid(device):
+    """identity of the stream the next launches go to: scratch buffers and cached weight images are per stream, so that independent
+    phases of an iteration may run on concurrent streams (conf.multi_stream) without sharing mutable scratch memory"""
+    return torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+
+
 def _ws(tag, nfloats, device):
-    """Grow-only scratch buffer per (tag, device).  All kernels of one process run in stream order on the compute
-    stream, so a buffer can be handed to the next kernel as soon as the previous launch has been queued."""
-    key = (tag, device)
+    """Grow-only scratch buffer per (tag, device, stream).  The kernels of one stream run in order, so a buffer can be handed to the
+    next kernel as soon as the previous launch has been queued."""
+    key = (tag, device, _sid(device))
     buf = _workspaces.get(key)
     n = max(int(nfloats), 1)
     if buf is None or buf.numel() < n:
@@ -116,7 +122,7 @@ def _wprep(w, KH, KW, Cin, Cout, mode, wkey=None):
         out = _ws('wprep%d' % mode, w.numel(), w.device)[:w.numel()]
         N.call('mmseg_conv2d_wprep', w, out, KH, KW, Cin, Cout, mode)
         return out
-    key = (wkey, w.data_ptr(), mode)
+    key = (wkey, w.data_ptr(), mode, _sid(w.device))
     ent = _wprep_cache.get(key)
     if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == w.numel():
         return ent[1]
@@ -129,7 +135,7 @@ def _wprep(w, KH, KW, Cin, Cout, mode, wkey=None):
 def _wprep_col8(w, Cout, wkey=None):
     """fast-path weight image of a 3x3 kernel with 8 input channels read as a 1x1 kernel over the 96-column im2col rows of
     mmseg_im2col8_t: [72][Cout] + 24 zero rows -> [Cout][96]; cached per weight version like _wprep"""
-    key = (wkey, w.data_ptr(), 'col8')
+    key = (wkey, w.data_ptr(), 'col8', _sid(w.device))
     ent = _wprep_cache.get(key) if wkey is not None else None
     if ent is not None and ent[0] == _weight_version[0]:
         return ent[1]
@@ -150,7 +156,7 @@ def _wprep_parity_all(w, KH, KW, Cin, Cout, stride, taps, wkey=None):
     mmseg_conv2d_dgrad_parity_all); cached per weight version like _wprep."""
     sizes = [taps[0][qh] * taps[1][qw] * Cin * Cout for qh in range(stride) for qw in range(stride)]
     n = sum(sizes)
-    key = (wkey, w.data_ptr(), 'parity_all', stride)
+    key = (wkey, w.data_ptr(), 'parity_all', stride, _sid(w.device))
     ent = _wprep_cache.get(key) if wkey is not None else None
     if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == n:
         return ent[1]
@@ -355,7 +361,7 @@ def conv2d_bn_infer(x, w, cbias, gamma, beta, mov_mean, mov_var, relu=False, x2=
     Ho, Wo, ph, pw = _conv_geometry(H, W, KH, KW, 1, 'same')
     # folded scale / bias: cached per layer until the weights or the moving statistics change (a pool evaluates every
     # encoder layer four times per iteration with the same parameters)
-    key = (wkey, gamma.data_ptr(), 'bnfold')
+    key = (wkey, gamma.data_ptr(), 'bnfold', _sid(gamma.device))
     ent = _bnfold_cache.get(key) if wkey is not None else None
     if ent is not None and ent[0] == (_weight_version[0], _bn_state_version[0]):
         ss = ent[1]

@@ -123,3 +123,49 @@ def test_sync_batchnorm_kernels_single_rank_equal_plain_batchnorm():
     assert abs(got[0] - ref[0]) <= 1e-5 * max(1.0, abs(ref[0]))
     assert np.abs(got[1] - ref[1]).max() <= 2e-5 * max(1.0, np.abs(ref[1]).max()), np.abs(got[1] - ref[1]).max()
     assert np.abs(got[2] - ref[2]).max() <= 1e-5, np.abs(got[2] - ref[2]).max()
+
+
+def _run_executor(force_dp, multi_stream):
+    from multimodal_segmentation_amd import nn
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
+    from multimodal_segmentation_amd.parallel import dp
+    nn.set_default_device('cuda:0')
+    np.random.seed(77)
+    conf = Hh.make_conf(dafnet_config_chaos, H, batch_size=4, multi_stream=multi_stream)
+    model = DAFNet(conf)
+    model.build()
+    dp.enable(force_dp, force=force_dp)
+    if force_dp:
+        dp.sync_model(model)
+    model.Enc_Modality._eps_rng = None
+    ex = DAFNetExecutor(conf, model)
+    np.random.seed(78)
+    ex.init_train_data(slices_per_volume=3)
+    losses = {n: [] for n in ex.get_loss_names()}
+    for _ in range(3):
+        ex.train_batch(losses)
+    torch.cuda.synchronize()
+    ms = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
+    out = [m.arena.detach().cpu().numpy().copy() for m in ms]
+    dp.enable(False)
+    return out
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_iterations_with_concurrent_discriminator_streams_are_bitwise_the_plain_iterations():
+    """conf.multi_stream under data parallelism: the discriminator phases run on side streams, their gradient all-reduces are queued
+    from those streams (RCCL work objects waited on by the stream that issued them) -- three whole iterations equal the plain
+    single-stream, no-DP iterations bit for bit"""
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    ref = _run_executor(False, False)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        got = _run_executor(True, True)
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)

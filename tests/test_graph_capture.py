@@ -70,9 +70,11 @@ def test_discriminator_and_generator_steps_replayed_from_graphs_are_bitwise_the_
         assert np.array_equal(a, b)
 
 
-def test_executor_iterations_with_graphs_are_bitwise_the_eager_iterations():
-    """the whole DAFNetExecutor.train_batch with conf.hip_graphs (trainer steps AND the fake pools replayed from graphs): five
-    iterations end in bit-identical weights and per-iteration losses"""
+@pytest.mark.parametrize('switch', ['hip_graphs', 'multi_stream'])
+def test_executor_iterations_with_graphs_are_bitwise_the_eager_iterations(switch):
+    """the whole DAFNetExecutor.train_batch with conf.hip_graphs (trainer steps AND the fake pools replayed from graphs) or with
+    conf.multi_stream (the two discriminator phases on concurrent HIP streams): five iterations end in bit-identical weights and
+    per-iteration losses"""
     from multimodal_segmentation_amd import nn
     from multimodal_segmentation_amd.configuration import dafnet_config_chaos
     from multimodal_segmentation_amd.models.dafnet import DAFNet
@@ -83,7 +85,7 @@ def test_executor_iterations_with_graphs_are_bitwise_the_eager_iterations():
     ref_w = None
     for mode in (False, True):
         np.random.seed(123)
-        conf = Hh.make_conf(dafnet_config_chaos, 64, batch_size=4, hip_graphs=mode)
+        conf = Hh.make_conf(dafnet_config_chaos, 64, batch_size=4, **{switch: mode})
         model = DAFNet(conf)
         model.build()
         ms = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
@@ -99,7 +101,9 @@ def test_executor_iterations_with_graphs_are_bitwise_the_eager_iterations():
         losses = {n: [] for n in ex.get_loss_names()}
         for _ in range(5):
             ex.train_batch(losses)
-        if mode:
+        if mode and switch == 'multi_stream':
+            assert getattr(ex, '_streams', None) is not None, 'the concurrent-stream path did not run'
+        if mode and switch == 'hip_graphs':
             from multimodal_segmentation_amd import graphs
             assert isinstance(ex.mask_pools, graphs.GraphedCall) and any(st.graph is not None for st in ex.mask_pools.states.values())
             assert any(st.graph is not None for st in ex.image_pools.states.values())
