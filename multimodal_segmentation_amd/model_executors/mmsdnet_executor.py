@@ -70,8 +70,26 @@ class MMSDNetExecutor(DAFNetExecutor):
         epoch_loss['val_loss'].append(np.mean([l_mod1, l_mod2, l_mod2_s1def, l_mod2_fused]))
 
     def train_batch(self, epoch_loss):
-        self.train_batch_generators(epoch_loss)
-        self.train_batch_mask_discriminator(epoch_loss)
+        """mmsdnet_executor.py:238-252.  conf.multi_stream (build-defined, default True, bit-identical results): the LAST Z-regressor
+        step of the iteration (it trains the decoder and the modality encoder) and the mask-discriminator phase (it reads the
+        anatomy encoders, the fuser and the segmentor and trains D_Mask) touch disjoint weights, so they are queued on two HIP
+        streams -- same launches, same host order, same random streams (see DAFNetExecutor._train_discriminators)."""
+        ms = bool(self.conf.get('multi_stream', True)) and self.device.type == 'cuda' and not bool(self.conf.get('hip_graphs', False))
+        if not ms:
+            self.train_batch_generators(epoch_loss)
+            self.train_batch_mask_discriminator(epoch_loss)
+            return
+        deferred = self.train_batch_generators(epoch_loss, defer_last_zreg=True)
+        if getattr(self, '_streams', None) is None:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(2)]
+        sA, sB = self._streams
+        main = torch.cuda.current_stream(self.device)
+        sA.wait_stream(main); sB.wait_stream(main)
+        with torch.cuda.stream(sA):
+            self._z_regressor_step(*deferred)
+        with torch.cuda.stream(sB):
+            self.train_batch_mask_discriminator(epoch_loss)
+        main.wait_stream(sA); main.wait_stream(sB)
 
     def _five(self, m):
         """Dice only reads the first num_masks channels of target and prediction (costs.py:62-64); the kernel wants both
@@ -100,22 +118,34 @@ class MMSDNetExecutor(DAFNetExecutor):
         return [m_list[t] for t in m.seg_target_modalities(supervised)] + [1.0] * n + \
                [x_list[t] for t in m.rec_target_modalities()] + [0.0] * n
 
-    def train_batch_generators(self, epoch_loss, eps=None, z_list=None):
+    def train_batch_generators(self, epoch_loss, eps=None, z_list=None, defer_last_zreg=False):
+        """defer_last_zreg: do not run the last Z-regressor step but return its arguments (train_batch queues it beside the
+        discriminator phase)"""
         M = self.model.num_mod
+        last_sup = defer_last_zreg and not (self.conf.l_mix < 1)
+        last_unsup = defer_last_zreg and self.conf.l_mix < 1
+        deferred = None
         if self.conf.l_mix > 0:
             batch = next(self.gen_labelled)                              # x_1 .. x_M, m_1 .. m_M
             x_list = [_dev(x, self.device) for x in batch[:M]]
             m_list = [self._five(_dev(mk, self.device)) for mk in batch[M:]]
             h = self.model.supervised_trainer.fit(x_list, self.generator_targets(x_list, m_list, True), eps=eps)
             self._store(h, epoch_loss)
-            self._z_regressor_step(x_list, epoch_loss, z_list)
+            if last_sup:
+                deferred = (x_list, epoch_loss, z_list)
+            else:
+                self._z_regressor_step(x_list, epoch_loss, z_list)
         if self.conf.l_mix < 1:
             batch = next(self.gen_unlabelled)                            # x_1 .. x_M, m_1
             x_list = [_dev(x, self.device) for x in batch[:M]]
             m_list = [self._five(_dev(batch[M], self.device))] + [None] * (M - 1)
             h = self.model.unsupervised_trainer.fit(x_list, self.generator_targets(x_list, m_list, False), eps=eps)
             self._store(h, epoch_loss)
-            self._z_regressor_step(x_list, epoch_loss, z_list)
+            if last_unsup:
+                deferred = (x_list, epoch_loss, z_list)
+            else:
+                self._z_regressor_step(x_list, epoch_loss, z_list)
+        return deferred
 
     def _store(self, h, epoch_loss):
         epoch_loss['supervised_Mask'].append(self._loss(h, 'Segmentor_loss'))

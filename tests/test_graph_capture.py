@@ -112,3 +112,40 @@ def test_executor_iterations_with_graphs_are_bitwise_the_eager_iterations(switch
     assert l0 == l1, 'per-iteration losses differ between the eager and the graph-replayed executor'
     for a, b in zip(w0, w1):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('nmod,l_mix', [(2, 1.0), (3, 0.5)])
+def test_mmsdnet_iterations_on_concurrent_streams_are_bitwise_the_single_stream_iterations(nmod, l_mix):
+    """MMSDNetExecutor.train_batch with conf.multi_stream (the last Z-regressor step beside the mask-discriminator phase): four
+    iterations end in bit-identical weights"""
+    from multimodal_segmentation_amd import nn
+    from multimodal_segmentation_amd.configuration import mmsdnet_config_chaos, mmsdnet3_config_chaos
+    from multimodal_segmentation_amd.models.mmsdnet import MMSDNet
+    from multimodal_segmentation_amd.model_executors.mmsdnet_executor import MMSDNetExecutor
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    runs, ref_w = {}, None
+    for mode in (False, True):
+        np.random.seed(11)
+        conf = Hh.make_conf(mmsdnet_config_chaos if nmod == 2 else mmsdnet3_config_chaos, 64, batch_size=2, l_mix=l_mix, multi_stream=mode)
+        model = MMSDNet(conf)
+        model.build()
+        ms = model._all_component_models() if hasattr(model, '_all_component_models') else []
+        assert ms
+        if ref_w is None:
+            ref_w = [m.get_weights() for m in ms]
+        else:
+            for m, w in zip(ms, ref_w):
+                m.set_weights(w)
+        model.Enc_Modality._eps_rng = None
+        ex = MMSDNetExecutor(conf, model)
+        np.random.seed(12)
+        ex.init_train_data(slices_per_volume=2)
+        losses = {n: [] for n in ex.get_loss_names()}
+        for _ in range(4):
+            ex.train_batch(losses)
+        if mode:
+            assert getattr(ex, '_streams', None) is not None
+        runs[mode] = _state(ms)
+    for a, b in zip(runs[False], runs[True]):
+        assert np.array_equal(a, b)
