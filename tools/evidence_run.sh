@@ -35,6 +35,9 @@ done
 unset DTYPE IO
 echo pmc 16-bit kernels done
 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --graphs > $O/bench_f32_graphs.json 2> $O/bench_f32_graphs.err
+python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --multi-stream > $O/bench_f32_multistream.json 2> $O/bench_f32_multistream.err
+python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --multi-stream --dtype bf16 --act16 > $O/bench_bf16_act16_multistream.json 2> $O/bench_bf16_act16_multistream.err
+python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --multi-stream --decoder spade --dtype bf16 --act16 > $O/bench_spade_bf16_act16_multistream.json 2> $O/bench_spade_bf16_act16_multistream.err
 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --dtype bf16 > $O/bench_bf16.json 2> $O/bench_bf16.err
 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --dtype bf16 --act16 > $O/bench_bf16_act16.json 2> $O/bench_bf16_act16.err
 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --decoder spade > $O/bench_spade_f32.json 2> $O/bench_spade_f32.err

@@ -30,7 +30,8 @@ def run(*cmd):
 
 
 def bench_lines():
-    order = ['bench_f32', 'bench_f32_graphs', 'bench_bf16', 'bench_bf16_act16', 'bench_spade_f32', 'bench_spade_bf16',
+    order = ['bench_f32', 'bench_f32_graphs', 'bench_f32_multistream', 'bench_bf16', 'bench_bf16_act16', 'bench_bf16_act16_multistream',
+             'bench_spade_bf16_act16_multistream', 'bench_spade_f32', 'bench_spade_bf16',
              'bench_spade_bf16_act16', 'bench_mmsdnet3_320_f16', 'bench_mmsdnet3_320_f16_act16', 'bench_lmix01']
     out = []
     for name in order:
