@@ -281,8 +281,7 @@ class DAFNetExecutor(Executor):
         for 256 CUs) then run beside the other phase's full-size inference convolutions instead of alone.  The host issues the
         same launches in the same order (same random streams); scratch buffers and cached weight images are per stream (ops._sid).
         Under data parallelism every rank queues the same collectives in the same order, each behind the launches of its own stream."""
-        # (not combined with conf.hip_graphs: replaying recorded steps from side streams did not reproduce the eager results)
-        if not (bool(self.conf.get('multi_stream', False)) and self.device.type == 'cuda' and not bool(self.conf.get('hip_graphs', False))):
+        if not (bool(self.conf.get('multi_stream', False)) and self.device.type == 'cuda'):
             self.train_batch_mask_discriminator(epoch_loss)
             self.train_batch_image_discriminator(epoch_loss)
             return

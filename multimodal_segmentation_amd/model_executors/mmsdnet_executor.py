@@ -74,7 +74,7 @@ class MMSDNetExecutor(DAFNetExecutor):
         step of the iteration (it trains the decoder and the modality encoder) and the mask-discriminator phase (it reads the
         anatomy encoders, the fuser and the segmentor and trains D_Mask) touch disjoint weights, so they are queued on two HIP
         streams -- same launches, same host order, same random streams (see DAFNetExecutor._train_discriminators)."""
-        ms = bool(self.conf.get('multi_stream', False)) and self.device.type == 'cuda' and not bool(self.conf.get('hip_graphs', False))
+        ms = bool(self.conf.get('multi_stream', False)) and self.device.type == 'cuda'
         if not ms:
             self.train_batch_generators(epoch_loss)
             self.train_batch_mask_discriminator(epoch_loss)

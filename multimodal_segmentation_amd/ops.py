@@ -21,7 +21,14 @@ _workspaces = {}
 def _sid(device):
     """identity of the stream the next launches go to: scratch buffers and cached weight images are per stream, so that independent
     phases of an iteration may run on concurrent streams (conf.multi_stream) without sharing mutable scratch memory"""
-    return torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0
+    if device.type != 'cuda':
+        return 0
+    from . import graphs
+    st = graphs._recording
+    if st is not None and st.mode == 'capture':
+        return ('graph', id(st))       # a recorded step owns its scratch: torch records every graph on one shared capture stream,
+                                       # and two recorded steps may later be replayed on concurrent streams
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _ws(tag, nfloats, device):

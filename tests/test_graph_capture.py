@@ -70,7 +70,7 @@ def test_discriminator_and_generator_steps_replayed_from_graphs_are_bitwise_the_
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize('switch', ['hip_graphs', 'multi_stream'])
+@pytest.mark.parametrize('switch', ['hip_graphs', 'multi_stream', 'hip_graphs+multi_stream'])
 def test_executor_iterations_with_graphs_are_bitwise_the_eager_iterations(switch):
     """the whole DAFNetExecutor.train_batch with conf.hip_graphs (trainer steps AND the fake pools replayed from graphs) or with
     conf.multi_stream (the two discriminator phases on concurrent HIP streams): five iterations end in bit-identical weights and
@@ -85,7 +85,7 @@ def test_executor_iterations_with_graphs_are_bitwise_the_eager_iterations(switch
     ref_w = None
     for mode in (False, True):
         np.random.seed(123)
-        conf = Hh.make_conf(dafnet_config_chaos, 64, batch_size=4, **{switch: mode})
+        conf = Hh.make_conf(dafnet_config_chaos, 64, batch_size=4, **{k: mode for k in switch.split('+')})
         model = DAFNet(conf)
         model.build()
         ms = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
@@ -101,9 +101,9 @@ def test_executor_iterations_with_graphs_are_bitwise_the_eager_iterations(switch
         losses = {n: [] for n in ex.get_loss_names()}
         for _ in range(5):
             ex.train_batch(losses)
-        if mode and switch == 'multi_stream':
+        if mode and 'multi_stream' in switch:
             assert getattr(ex, '_streams', None) is not None, 'the concurrent-stream path did not run'
-        if mode and switch == 'hip_graphs':
+        if mode and 'hip_graphs' in switch:
             from multimodal_segmentation_amd import graphs
             assert isinstance(ex.mask_pools, graphs.GraphedCall) and any(st.graph is not None for st in ex.mask_pools.states.values())
             assert any(st.graph is not None for st in ex.image_pools.states.values())
