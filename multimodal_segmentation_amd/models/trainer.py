@@ -80,6 +80,7 @@ class Trainer(object):
         assert epochs == 1
         inputs = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
         targets = list(targets) if isinstance(targets, (list, tuple)) else [targets]
+        graph_kw = {k: v for k, v in graph_kw.items() if v is not None}      # (eps=None etc.: the graph functions' defaults)
         if self.use_graph and not graph_kw and not dp.enabled() and self.device.type == 'cuda':
             key = graphs.signature(inputs, targets)
             st = self._graphs.get(key)
