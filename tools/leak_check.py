@@ -13,7 +13,7 @@ cfg['d_mask_params']['input_shape'] = (H, H, 4); cfg['d_image_params']['input_sh
 cfg['batch_size'] = B; cfg['n_pairs'] = 1; cfg['folder'] = '/tmp/mmseg_leak'
 for kv in os.environ.get('CONF', '').split(','):       # e.g. CONF=compute_dtype=bf16,act_storage=half,decoder_type=spade,hip_graphs=1
     if '=' in kv:
-        k, v = kv.split('=', 1); cfg[k] = (v == '1') if k == 'hip_graphs' else v
+        k, v = kv.split('=', 1); cfg[k] = (v == '1') if k in ('hip_graphs', 'multi_stream') else v
 conf = EasyDict(cfg); model = DAFNet(conf); model.build()
 ex = DAFNetExecutor(conf, model); ex.keep_losses_on_device = True; ex.init_train_data(slices_per_volume=4)
 losses = {n: [] for n in ex.get_loss_names()}
