@@ -18,6 +18,8 @@ Extra fields of the JSON line:
   roofline_kernels -- the same entry for every convolution kernel instance with >= 0.5 ms of GPU time per step
   roofline_family  -- the two families of round 1 (all forward + data-gradient launches / all weight-gradient launches)
   cpu_baseline     -- the oracle (torch-CPU restatement, "port") timed on this box's host cores on a bounded sample
+  multi_stream     -- informational: the same iterations re-timed with conf.multi_stream (discriminator phases on concurrent HIP streams,
+                      bit-identical results); NOT `value` -- time-shared kernels would misstate the per-kernel roofline entries
 """
 import argparse
 import json
@@ -276,6 +278,7 @@ def main():
                     help='conf.multi_stream: the mask- and image-discriminator phases of an iteration on concurrent HIP streams (bit-identical '
                          'results, ~2.5 %% faster iteration; off by default because the elapsed time of a kernel that shares the GPU with '
                          "another stream's kernels no longer measures that kernel: the per-kernel roofline entries would read low)")
+    ap.add_argument('--no-multi-stream-region', action='store_true', help='skip the informational second timed region with conf.multi_stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
     ap.add_argument('--conv-breakdown', action='store_true', help='per-shape convolution table on stderr')
@@ -403,6 +406,28 @@ def main():
     passes = (1 if args.l_mix > 0 else 0) + (1 if args.l_mix < 1 else 0)
     pairs = world * args.batch * args.steps * passes
     value = pairs / dt
+    # informational second region (not `value`): the same iterations with conf.multi_stream -- the discriminator phases on concurrent
+    # HIP streams, bit-identical results.  Kept out of the headline because per-kernel elapsed times of time-shared kernels would
+    # misstate the `roofline` entries.
+    multi = None
+    if args.model == 'dafnet' and not args.multi_stream and not args.graphs and not args.no_multi_stream_region:
+        conf['multi_stream'] = True
+        for _ in range(2):
+            ex.train_batch(losses)
+        sync()
+        k2 = min(args.steps, 10)
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            ex.train_batch(losses)
+        sync()
+        dt2 = time.perf_counter() - t1
+        conf['multi_stream'] = False
+        if world > 1:
+            tmax = torch.tensor([dt2], device='cuda')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt2 = float(tmax.item())
+        multi = {'value': world * args.batch * k2 * passes / dt2, 'unit': 'paired slices/s', 'ms_per_step': 1000.0 * dt2 / k2, 'steps': k2,
+                 'note': 'conf.multi_stream: mask- and image-discriminator phases on concurrent HIP streams; same results bit for bit'}
     line = {
         'metric': '2D slices/sec %s train step, %dx%dx2-modality bs=%d/GPU' % ('DAFNet' if args.model == 'dafnet' else 'MMSDNet',
                                                                                 H, H, args.batch),
@@ -467,6 +492,8 @@ def main():
                 fam[kind]['traffic'] = traffic.get('families', {}).get('conv_fwd' if kind == 'conv_fwd_kernel' else 'conv_wgrad', {}).get('hbm_bytes_per_launch')
         if fam:
             line['roofline_family'] = fam
+        if multi is not None:
+            line['multi_stream'] = multi
         if world == 1 and not args.no_cpu_baseline and args.model == 'dafnet':
             _progress('cpu baseline (oracle, bounded sample)')
             line['cpu_baseline'] = cpu_baseline(H, args.decoder, args.batch)
