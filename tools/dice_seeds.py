@@ -86,7 +86,8 @@ def summary(paths):
     mean = float(np.mean(diffs))
     sd = float(np.std(diffs, ddof=1)) if n > 1 else float('nan')
     tcrit = {2: 12.71, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365, 9: 2.306, 10: 2.262, 11: 2.228, 12: 2.201,
-             13: 2.179, 14: 2.160, 15: 2.145, 16: 2.131}.get(n, 1.96)     # Student t, 97.5 %, n - 1 degrees of freedom
+             13: 2.179, 14: 2.160, 15: 2.145, 16: 2.131, 17: 2.120, 18: 2.110, 19: 2.101, 20: 2.093, 21: 2.086, 22: 2.080, 23: 2.074,
+             24: 2.069, 25: 2.064, 26: 2.060, 27: 2.056, 28: 2.052, 29: 2.048, 30: 2.045}.get(n, 1.96)     # Student t, 97.5 %, n - 1 degrees of freedom
     half = tcrit * sd / math.sqrt(n) if n > 1 else float('nan')
     print('n = %d seeds: Dice product %.4f +- %.4f (sd), oracle %.4f +- %.4f (sd)' % (n, np.mean(pm), np.std(pm, ddof=1) if n > 1 else 0,
                                                                                      np.mean(om), np.std(om, ddof=1) if n > 1 else 0))
