@@ -40,6 +40,7 @@ def set_default_device(dev):
 
 
 _anchors = {}
+_BN_BIAS_GRAD = os.environ.get('MMSEG_BN_BIAS_GRAD', '0') == '1'
 
 
 def anchor(device):
@@ -340,7 +341,8 @@ def conv_bn(m, cname, bname, x, training, relu=False, x2=None, upsample=False, y
     conv_dt = half if (half is not None and c1 % 32 == 0 and c2 % 32 == 0 and Cout % 64 == 0) else torch.float32
     bn_dt = half if (half is not None and y16 and Cout % 64 == 0) else torch.float32
     if training or torch.is_grad_enabled():
-        l = conv(m, cname, x, x2=x2, upsample=upsample, bias_grad=not training, out_dtype=conv_dt)
+        # (MMSEG_BN_BIAS_GRAD=1, experiments only: compute the -- mathematically zero -- bias gradient like the reference does)
+        l = conv(m, cname, x, x2=x2, upsample=upsample, bias_grad=(not training) or _BN_BIAS_GRAD, out_dtype=conv_dt)
         return bn(m, bname, l, training, relu=relu, out_dtype=bn_dt)
     return ops.conv2d_bn_infer(x, w.data, b.data if b is not None else None, m.params[bname + '/gamma'].data,
                                m.params[bname + '/beta'].data, m.params[bname + '/moving_mean'].data,
