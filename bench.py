@@ -232,17 +232,26 @@ def cpu_baseline(H, decoder, B, limit_s=240):
                           % (H, H, B, limit_s, type(exc).__name__)}
 
 
-def launch_ranks(n):
-    """start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child; -> its return code"""
+def launch_ranks(n, dry_run=False):
+    """start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a CHILD process (this parent has not
+    touched the GPU and never replaces itself); -> the child's return code.  `dry_run`: print the command and the environment it
+    would get as one JSON line instead of starting it (tests/test_bench_cli.py)."""
     import socket
     import subprocess
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
+    argv = [a for a in sys.argv[1:] if a != '--dry-run']
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):          # the launcher sets these for its ranks
+        env.pop(k, None)
+    if dry_run:
+        print(json.dumps({'dry_run': True, 'cmd': cmd, 'cwd': ROOT,
+                          'env': {k: env[k] for k in ('HSA_ENABLE_IPC_MODE_LEGACY',) if k in env}}))
+        return 0
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
@@ -284,6 +293,7 @@ def main():
     ap.add_argument('--conv-breakdown', action='store_true', help='per-shape convolution table on stderr')
     ap.add_argument('--conv-timer-stride', type=int, default=7, help='time every n-th convolution launch with HIP events')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--dry-run', action='store_true', help='with --gpus N > 1: print the launcher command instead of starting the ranks')
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_measure(args.size, args.decoder, args.batch)))
@@ -293,7 +303,7 @@ def main():
         # `python bench.py --gpus N` on its own: this parent has not touched the GPU (no torch.cuda call so far) and starts the
         # N ranks as a CHILD process (never exec from a process that may own a GPU context), relays their output and exits with
         # the child's return code
-        sys.exit(launch_ranks(args.gpus))
+        sys.exit(launch_ranks(args.gpus, args.dry_run))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -388,6 +398,7 @@ def main():
     sync()
     _progress('timed region')
     timer.enabled = True
+    dp.counters(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ex.train_batch(losses)
@@ -398,10 +409,22 @@ def main():
     if args.conv_breakdown and rank == 0:
         torch.cuda.synchronize()
         timer.breakdown(args.steps)
+    dp_counters = dp.counters()
+    per_rank_ms = [1000.0 * dt / args.steps]
+    replicas_ok = None
     if world > 1:
+        mine = torch.tensor([dt], device='cuda')
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_ms = [1000.0 * float(t.item()) / args.steps for t in allt]
         tmax = torch.tensor([dt], device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # self-verification of a multi-GPU run: after the timed iterations every rank must hold bit-identical weights (the gradient
+        # all-reduce is the only thing that keeps replicas together; a wrong or missing collective shows here, not in the rate)
+        replicas_ok, checksum = dp.replicas_identical(all_models)
+        if not replicas_ok:
+            raise SystemExit('bench.py: rank %d: the weight replicas DIVERGED during the timed region (checksums %s)' % (rank, checksum[:6]))
 
     passes = (1 if args.l_mix > 0 else 0) + (1 if args.l_mix < 1 else 0)
     pairs = world * args.batch * args.steps * passes
@@ -449,7 +472,17 @@ def main():
     key = (args.decoder if args.model == 'dafnet' else ('mmsdnet' if args.modalities == 2 else 'mmsdnet3'), H)
     if key in TFLOP_PER_PAIR:
         line['conv_tflops_whole_step'] = TFLOP_PER_PAIR[key] * value / world
-        line['conv_roofline_frac_whole_step'] = TFLOP_PER_PAIR[key] * value / world / FP32_MFMA_PEAK_TFLOPS
+        # against the MFMA peak of the dtype the convolutions multiply in (fp32: 157.3; bf16 / fp16: 2500 TFLOP/s)
+        line['conv_roofline_frac_whole_step'] = TFLOP_PER_PAIR[key] * value / world / (
+            BF16_MFMA_PEAK_TFLOPS if args.dtype in ('bf16', 'f16') else FP32_MFMA_PEAK_TFLOPS)
+    line['per_rank_ms_per_step'] = per_rank_ms
+    if world > 1:
+        st = max(dp_counters['steps'], 1)
+        line['dp'] = {'trainer_steps': dp_counters['steps'], 'collectives_per_iteration': dp_counters['collectives'] / float(args.steps),
+                      'overlapped_with_backward_per_iteration': dp_counters['overlapped'] / float(args.steps),
+                      'replicas_identical_after_timed_region': replicas_ok,
+                      'note': 'gradient all-reduces per iteration (one per component arena and trainer step) and how many of them were '
+                              'issued while the backward pass was still being queued; %d trainer steps timed' % st}
     if rank == 0:
         summ = timer.summary() if not args.no_conv_timer else {}
         # HBM bytes per launch from rocprofv3 PMC passes of THIS workload (tools/pmc_traffic.py), keyed by workload and kernel

@@ -10,10 +10,12 @@ The reference is run from its repository root, so its callers import `model_comp
     from model_components import decoder               # IS multimodal_segmentation_amd.model_components.decoder
     importlib.import_module('models.dafnet').DAFNet    # what experiment.py:115-118 does
 
-`install()` puts ONE finder on `sys.meta_path` that answers exactly those names by importing the package-qualified
-module and registering the same module object under the short name -- no second copy of any module exists, so class
-identities, module-level caches and the kernel library handle are shared.  Opt-in: the generic names (`utils`,
-`models`, ...) are only claimed after `install()`; `uninstall()` removes the finder and the aliases.
+`install()` puts ONE finder at the END of `sys.meta_path` that answers exactly those names by importing the
+package-qualified module and registering the same module object under the short name -- no second copy of any module
+exists, so class identities, module-level caches and the kernel library handle are shared.  Because it is the LAST
+finder, a real top-level module or package of one of these generic names (`utils`, `models`, ...) that the regular path
+finders can locate keeps precedence: the aliases never shadow user or third-party code, they only answer names nobody
+else provides.  Opt-in: nothing is claimed before `install()`; `uninstall()` removes the finder and the aliases.
 """
 import importlib
 import importlib.abc
@@ -61,7 +63,7 @@ _finder = _AliasFinder()
 def install():
     """claim the reference's top-level module names (idempotent)"""
     if _finder not in sys.meta_path:
-        sys.meta_path.insert(0, _finder)
+        sys.meta_path.append(_finder)
     return _finder
 
 

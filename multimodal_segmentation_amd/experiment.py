@@ -127,7 +127,7 @@ class Experiment(object):
             self.save_config(conf)               # training adds keys (e.g. unlabelled counts)
         if dp.is_main():                          # replicas are identical after training: one rank evaluates and writes
             executor.test()
-        dp.barrier()
+        dp.host_barrier()                         # not a GPU collective: the other ranks may wait longer than RCCL's watchdog allows
 
     def run(self, argv=None):
         args = parse_arguments(argv)

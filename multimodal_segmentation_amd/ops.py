@@ -268,8 +268,8 @@ class _Conv2d(torch.autograd.Function):
         M = B * Ho * Wo
         bias_done = False
         if act:
-            g = _new(dy.shape, dy)
             assert _h(dy) == _h(y), 'the gradient of a tensor is stored like the tensor'
+            g = _new(dy.shape, dy, dy.dtype)      # act16_bwd_kernel stores dx with dy's element type
             if ctx.bgrad is not None and Cout % 64 == 0:
                 # activation gradient and bias gradient (column sums of g) in one pass over dy / y
                 ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', M, Cout), dy.device)
@@ -324,8 +324,7 @@ class _Conv2d(torch.autograd.Function):
                 # the Keras kernel [KH, KW, Cin, Cout] read as [taps * Cin][Cout] IS the fast layout of that 1x1 convolution
                 # (in the reduced-precision modes the image holds 16-bit elements: converted copy, cached like the other images)
                 wimg = w.reshape(-1) if N.call('mmseg_get_conv_precision') == 0 else _wprep(w, KH, KW, Cin, Cout, 2, ctx.wkey)
-                N.call('mmseg_conv2d_fwd', g, None, None, wimg, None, T, None, B, Ho, Wo, Cout, 0, Ho, Wo, nt, 1, 1, 1, 0, 0,
-                       0, 0, 0, 0.0, 0)
+                _conv_fwd_raw(g, None, None, wimg, None, T, None, B, Ho, Wo, Cout, 0, Ho, Wo, nt, 1, 1, 1, 0, 0, 0, 0, 0, 0.0, 0)
                 N.call('mmseg_conv2d_dgrad_tapsum', T, d1, B, H, W, Ho, Wo, Cin, KH, KW, ph, pw)
             elif tr and stride == 2 and C2 == 0 and not ups and N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0) and \
                     min(taps[0] + taps[1]) > 0:

@@ -62,6 +62,10 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         kw = {'device_id': torch.device('cuda', local_rank)} if (use_gpu and backend == 'nccl') else {}
         dist.init_process_group(backend, **kw)
+    if _state.get('host_group') is None and dist.get_backend() != 'gloo':
+        # a CPU-side group for waits of unbounded length (host_barrier): created collectively, here, by every rank
+        import datetime
+        _state['host_group'] = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=48))
     if use_gpu:
         from .. import nn
         nn.set_default_device('cuda:%d' % local_rank)
@@ -84,6 +88,19 @@ def sync_model(model):
 
 def barrier():
     if enabled():
+        dist.barrier()
+
+
+def host_barrier():
+    """wait for every rank WITHOUT a GPU collective: rank 0 evaluates the test split alone after training (experiment.py) while the
+    other ranks wait here -- a RCCL barrier would hit the process group's 10-minute watchdog on a real-size test pass.  Uses the
+    gloo side group created by init_from_env (48 h timeout); with a gloo default group the ordinary barrier is already host-side."""
+    if not enabled():
+        return
+    g = _state.get('host_group')
+    if g is not None:
+        dist.barrier(group=g)
+    else:
         dist.barrier()
 
 
@@ -174,10 +191,13 @@ class GradTracker(object):
     def finish(self):
         """reduce whatever has not been reduced yet (in model order: identical on every rank), wait, average"""
         _state['last_overlapped'] = len(self.works)     # collectives issued during the backward pass
+        _state['total_overlapped'] = _state.get('total_overlapped', 0) + len(self.works)
         for m in self.models:
             if id(m) in self.used and id(m) not in self.fired:
                 self._fire(m)
         _state['last_collectives'] = len(self.works)
+        _state['total_collectives'] = _state.get('total_collectives', 0) + len(self.works)
+        _state['total_steps'] = _state.get('total_steps', 0) + 1
         from .. import ops
         ws = float(dist.get_world_size())
         for m, w in self.works:
@@ -198,6 +218,43 @@ def finish(tracker):
         return
     _tracker[0] = None
     tracker.finish()
+
+
+def counters(reset=False):
+    """gradient collectives since the last reset: {'steps': trainer steps, 'collectives': arena all-reduces, 'overlapped': those issued
+    while the backward pass was still being queued} -- the evidence a first multi-GPU run prints beside its throughput"""
+    out = {'steps': _state.get('total_steps', 0), 'collectives': _state.get('total_collectives', 0),
+           'overlapped': _state.get('total_overlapped', 0)}
+    if reset:
+        _state['total_steps'] = _state['total_collectives'] = _state['total_overlapped'] = 0
+    return out
+
+
+def replica_checksums(models):
+    """[2 * len(models)] float64: (sum, sum of squares) of every model's weight arena AND non-trainable state on this rank"""
+    vals = []
+    for m in models:
+        for t in (m.arena, m.state_arena):
+            d = t.detach().double() if (t is not None and t.numel() > 0) else torch.zeros(1, dtype=torch.float64)
+            vals += [d.sum().reshape(1), (d * d).sum().reshape(1)]
+    return torch.cat(vals)
+
+
+def replicas_identical(models, check_state=False):
+    """-> (ok, local checksum list): every rank holds bit-identical weight arenas (all-reduce MAX == all-reduce MIN of the per-arena
+    checksums).  BatchNorm moving statistics are per-rank between epoch boundaries (ghost statistics), so the non-trainable state is
+    only included on request (after dp.average_state).  Verification plumbing of bench.py / the tests, not part of the step."""
+    cs = replica_checksums(models)
+    if not check_state:
+        keep = torch.tensor([i for i in range(cs.numel()) if (i // 2) % 2 == 0])
+        cs = cs[keep]
+    if not enabled():
+        return True, cs.tolist()
+    dev = models[0].arena.device if dist.get_backend() == 'nccl' else torch.device('cpu')
+    hi, lo = cs.to(dev).clone(), cs.to(dev).clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return bool(torch.equal(hi, lo)), cs.tolist()
 
 
 def broadcast_models(models, src=0):

@@ -154,6 +154,56 @@ def test_batchnorm_maxpool_upsample_typed_io(hx, hy, mode):
         assert torch.equal(u, u_ref.to(mode))
 
 
+@pytest.mark.parametrize('act', [1, 2, 3])
+@pytest.mark.parametrize('C,bias', [(128, True), (64, True), (24, False)])
+def test_activation_gradient_16bit(C, bias, act, mode):
+    """mmseg_act_bwd_bias_t with 16-bit dy / y / dx (the gradient of an activated convolution whose output is stored in 16 bits --
+    the SPADE units' 128-channel hidden tensor) against act_bwd + colsum on the widened tensors: dx is bit for bit the rounding of the
+    fp32 result, the bias gradient the column sums of the stored (rounded) values."""
+    M = 3 * 40 * 40
+    alpha = 0.2
+    y = rnd(M, C, seed=21).to(mode).to(DEV)
+    if act == 3:
+        y = torch.tanh(y.float()).to(mode)
+    dy = rnd(M, C, seed=22).to(mode).to(DEV)
+    ref = torch.empty(M, C, device=DEV)
+    N.call('mmseg_act_bwd', dy.float(), y.float(), ref, M * C, act, alpha)
+    dx = torch.full((M, C), float('nan'), device=DEV, dtype=mode)
+    h = 1 if mode == torch.bfloat16 else 2
+    if bias:
+        bg = torch.full((C,), 0.5, device=DEV)
+        ws = torch.empty(N.call('mmseg_colsum_workspace_floats', M, C), device=DEV)
+        N.call('mmseg_act_bwd_bias_t', dy, y, dx, bg, ws, M, C, act, alpha, 1, h)
+        want = 0.5 + ref.to(mode).double().sum(0)      # the bias gradient sums the STORED values (what the weight / data gradients read)
+        assert (bg.double() - want).abs().max() <= 2e-4 * max(1.0, float(want.abs().max()))
+    else:
+        N.call('mmseg_act_bwd_bias_t', dy, y, dx, None, None, M, C, act, alpha, 0, h)
+    assert torch.equal(dx, ref.to(mode))
+
+
+def test_activated_conv_with_16bit_output_has_a_correct_backward(mode):
+    """ops.conv2d(act='relu', out_dtype=half) -- `spade_hidden`: 8 -> 128, the only activated convolution stored in 16 bits -- forward
+    and backward through the autograd node against the fp32-storage node (round-2 defect: the activation gradient was written in
+    16 bits into an fp32 buffer and read back as fp32 by the weight- and data-gradient launches)."""
+    B, H, Cin, Cout = 2, 32, 8, 128
+    x = rnd(B, H, H, Cin, seed=31).to(mode).float().to(DEV)
+    w = (rnd(3, 3, Cin, Cout, seed=32) * 0.1).to(DEV)
+    b = (rnd(Cout, seed=33) * 0.1).to(DEV)
+    dy = rnd(B, H, H, Cout, seed=34).to(mode).to(DEV)
+    out = {}
+    for dt in (torch.float32, mode):
+        xg = x.clone().requires_grad_(True)
+        wg, bg = torch.zeros_like(w), torch.zeros_like(b)
+        anchor = torch.zeros(1, device=DEV, requires_grad=True)
+        y = P.conv2d(xg, w, b, 1, 'same', 'relu', 0.0, wgrad=wg, bgrad=bg, anchor=anchor, out_dtype=dt)
+        assert y.dtype == dt
+        y.backward(dy.to(dt))
+        out[dt] = (y.float(), xg.grad.float(), wg, bg)
+    for a, b_, name, tol in zip(out[torch.float32], out[mode], ('y', 'dx', 'dw', 'db'), (1e-2, 2e-2, 2e-2, 2e-2)):
+        err = float((a - b_).norm() / a.norm())
+        assert err <= tol, '%s: rel L2 %.3e' % (name, err)
+
+
 @pytest.mark.parametrize('dt,decoder', [('bf16', 'film'), ('fp16', 'film'), ('bf16', 'spade')])
 def test_generator_step_with_16bit_trunk_storage_close_to_fp32_storage(dt, decoder):
     """conf.act_storage = 'half' at the model level: a teacher-forced DAFNet generator step with the trunk's activations and gradients
@@ -169,7 +219,7 @@ def test_generator_step_with_16bit_trunk_storage_close_to_fp32_storage(dt, decod
     B1 = np.ones((B, 1), np.float32)
     tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [B1] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [B1] * 4 + \
          [np.zeros(B, np.float32)] * 2 + [d['z1'], d['z2']]
-    res, teacher, ref_w = {}, None, None
+    res, grads, teacher, ref_w = {}, {}, None, None
     try:
         for storage in ('fp32', 'half'):
             conf = Hh.make_conf(dafnet_config_chaos, H, compute_dtype=dt, act_storage=storage, decoder_type=decoder)
@@ -186,6 +236,7 @@ def test_generator_step_with_16bit_trunk_storage_close_to_fp32_storage(dt, decod
             if teacher is None:
                 teacher = [model.last_factors['s1'].detach().clone(), model.last_factors['s2'].detach().clone()]
             res[storage] = {k: h.history[k][0] for k in h.history.keys()}
+            grads[storage] = Hh.product_grads(model)
             if storage == 'half':
                 # the segmentor's first block hands a 16-bit tensor to its second convolution
                 x = torch.zeros(B, H, H, 8, device='cuda')
@@ -205,3 +256,23 @@ def test_generator_step_with_16bit_trunk_storage_close_to_fp32_storage(dt, decod
         tol = 6e-2 if k in ('loss', 'D_Mask_loss', 'D_Image1_loss', 'D_Image2_loss') else 3e-2
         assert np.isfinite(res['half'][k]) and abs(res['half'][k] - v) <= tol * max(1.0, abs(v)), (k, v, res['half'][k])
     assert any(abs(res['half'][k] - v) > 1e-7 for k, v in res['fp32'].items())
+    # the BACKWARD pass (the losses above are forward quantities): weight gradients of the 16-bit-storage step against the fp32-storage
+    # step, relative L2 per tensor -- for the components DOWNSTREAM of the teacher-forced anatomies (decoder, segmentor, modality
+    # encoder, fuser).  The anatomy encoders' gradients are left out: measured against the fp64 oracle they carry 40 % (bf16) / 18 %
+    # (fp16) noise at this size in EVERY 16-bit implementation, the fp32-storage oracle included
+    # (profiles/r03_gradient_errors_*_bf16_cuda.txt), so they cannot tell a defect from rounding.  Downstream the noise is 4 % (FiLM) /
+    # 24 % (SPADE, 30 convolutions with InstanceNorm); a gradient tensor written with the wrong element type (round 2's activated
+    # 16-bit convolution `spade_hidden`) is off by O(1) in every SPADE unit.
+    worst = []
+    for k, g32 in grads['fp32'].items():
+        if not k.startswith(('DEC/', 'SEG/', 'EM/', 'FUS/')):
+            continue
+        g16 = grads['half'][k]
+        assert np.isfinite(g16).all(), k
+        nrm = np.linalg.norm(g32)
+        if nrm < 1e-9:
+            continue
+        worst.append((float(np.linalg.norm(g16 - g32) / nrm), k))
+    worst.sort(reverse=True)
+    print('worst downstream gradient rel-L2 (16-bit vs fp32 storage):', worst[:6])
+    assert worst[0][0] <= (0.5 if decoder == 'spade' else 0.15), worst[:6]

@@ -52,6 +52,20 @@ def _oracle(model, conf):
                                    w_rec_X=conf.w_rec_X))
 
 
+def _dump_gradient_report(tag, report):
+    """MMSEG_PARITY_REPORT=<dir>: the MEASURED per-tensor gradient errors (relative L2 vs the fp64 oracle) beside the fp32 oracle's
+    own error against fp64 -- the evidence the gradient bars are set from (profiles/r03_gradient_errors_*.txt)"""
+    import os
+    out = os.environ.get('MMSEG_PARITY_REPORT')
+    if not out:
+        return
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'gradient_errors_%s.txt' % tag), 'w') as f:
+        f.write('# tensor, product rel-L2 error vs the reference oracle, fp32-oracle rel-L2 error vs the fp64 oracle (noise floor)\n')
+        for ratio, err, floor, k in sorted(report, key=lambda r: -r[1]):
+            f.write('%-44s %.3e %.3e\n' % (k, err, floor))
+
+
 def _cmp(a, b, name, tol=TOL):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
@@ -78,20 +92,23 @@ def test_generator_step_reduced_precision_vs_operand_rounding_oracle(decoder, mo
     case) every element whose pre-rounding value differs in the last fp32 bits may round to the other 16-bit neighbour, so the two
     implementations decorrelate at the 16-bit noise level -- measured: pre-rounding softmax within 3e-2.  The bars are therefore
     the 16-bit ones: softmax 8e-2, everything downstream of the (teacher-forced) anatomies and every loss term 5e-2 (measured: 2.9e-2
-    on the SPADE reconstruction, a 30-convolution decoder with InstanceNorm), gradients
-    0.3 in relative L2 (their data- / weight-gradient launches also round the incoming gradient, which the oracle does not)."""
+    on the SPADE reconstruction, a 30-convolution decoder with InstanceNorm), gradients against the per-tensor noise floor of the
+    operand-rounding oracle itself (see below)."""
     from multimodal_segmentation_amd import ops as P
     from oracle import ops as OO
     prev = OO.set_conv_operand_rounding(torch.bfloat16 if mode == 'bf16' else torch.float16)
     try:
-        _generator_step_check(decoder, 64, True, 'cuda', compute_dtype=mode, out_tol=5e-2, soft_tol=8e-2, grad_floor=0.3)
+        # gradients: the 16-bit modes are intrinsically noisy on the encoders' tensors -- the fp32 ORACLE with emulated operand rounding
+        # is 40 % (bf16) / 18 % (fp16) in relative L2 away from the fp64 one (measured, profiles/r03_gradient_errors_*_bf16_cuda.txt), the
+        # product 41 % / 20 %: the bar is 1.5 x that per-tensor floor (two realisations of the same rounding noise), at least 0.1
+        _generator_step_check(decoder, 64, True, 'cuda', compute_dtype=mode, out_tol=5e-2, soft_tol=8e-2, grad_floor=0.1, grad_factor=1.5)
     finally:
         OO.set_conv_operand_rounding(prev)
         P.set_conv_precision('fp32')
 
 
-def _generator_step_check(decoder, H, supervised, device, compute_dtype='fp32', out_tol=TOL, grad_floor=3e-2, B=2,
-                          oracle_dtype=torch.float64, check_grads=True, soft_tol=None):
+def _generator_step_check(decoder, H, supervised, device, compute_dtype='fp32', out_tol=TOL, grad_floor=1e-2, B=2,
+                          oracle_dtype=torch.float64, check_grads=True, soft_tol=None, grad_factor=3.0):
     if device == 'cuda':
         nn.set_default_device('cuda:0')
     conf, model = _build(decoder, H, device, compute_dtype=compute_dtype)
@@ -159,12 +176,12 @@ def _generator_step_check(decoder, H, supervised, device, compute_dtype='fp32', 
         _cmp(h.history[k][0] / rel, v / rel, 'loss ' + k, out_tol)
     if not check_grads:
         return model, orc
-    # gradients of every generator weight.  fp32 arithmetic through ~60 layers with BatchNorm on few samples and
-    # ReLU / max-pool kinks is itself noisy against fp64 (the oracle run in fp32 deviates from the oracle run in fp64
-    # by up to 1e-1 of a tensor's max: the anatomy factors are piecewise constant, so whole regions sit on one
-    # pre-activation value and a 1e-6 perturbation can flip the ReLU mask of a region).  The bar is therefore relative
-    # L2 per tensor, at most max(5x the measured fp32 noise floor of the oracle, grad_floor); op-level gradients are
-    # checked tightly in test_ops_parity.py.
+    # gradients of every generator weight.  fp32 arithmetic through ~60 layers with BatchNorm on few samples and ReLU / max-pool
+    # kinks is itself noisy against fp64: the ORACLE run in fp32 deviates from the oracle run in fp64 by 0.5 % (64 x 64) to 1.5 %
+    # (192 x 192) in relative L2 on the encoders' tensors -- that is the noise floor of any fp32 implementation, measured per tensor
+    # in this very run (`floor`).  Round 3: the product's measured errors (profiles/r03_gradient_errors_*.txt: 5.8e-3 at 64 x 64,
+    # 1.7e-2 at 192 x 192, each within 1.3x of its floor) set the bar: relative L2 per tensor <= max(3 x floor, 1e-2).  Round 2's
+    # max(5 x floor, 3e-2) would have passed a 3 % systematic error; op-level gradients are checked to 2e-4 in test_ops_parity.py.
     pg = Hh.product_grads(model)
     report = []
     for k, g in orc.last_grads.items():
@@ -177,9 +194,10 @@ def _generator_step_check(decoder, H, supervised, device, compute_dtype='fp32', 
         nrm = max(np.linalg.norm(g), 1e-12)
         err = np.linalg.norm(pg[k] - g) / nrm
         floor = np.linalg.norm(grads32[k] - g) / nrm if grads32 is not None else 0.0
-        report.append((err / max(5 * floor, grad_floor), err, floor, k))
+        report.append((err / max(grad_factor * floor, grad_floor), err, floor, k))
     report.sort(reverse=True)
     print('worst gradient errors (ratio to tolerance, rel-L2 err, fp32-oracle noise floor):', report[:5])
+    _dump_gradient_report('%s_%d_%s_%s_%s' % (decoder, H, 'sup' if supervised else 'unsup', compute_dtype, device), report)
     for ratio, err, floor, k in report:
         assert ratio <= 1.0, 'grad %s: rel L2 err %.3e vs fp32 noise floor %.3e' % (k, err, floor)
     # BN moving statistics after the step

@@ -125,7 +125,22 @@ def _worker_body(rank, world, port, q):
     sig = torch.cat([m.arena.double().sum().reshape(1) for m in gens])
     gathered = [torch.zeros_like(sig) for _ in range(world)]
     dist.all_gather(gathered, sig)
-    q.put((rank, dm_after.numpy(), [g.numpy() for g in gathered], float(h.history['loss'][0]), tiny_grad, seg_grad, seg_state))
+    # ---- a FULL DAFNet iteration through the executor (generator fit, both pools, four discriminator fits) on per-rank data ----
+    from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
+    conf.batch_size = 1
+    ex = DAFNetExecutor(conf, model)
+    ex.init_train_data(device_resident=False, slices_per_volume=1)
+    all_models = gens + [model.D_Mask, model.D_Image1, model.D_Image2]
+    ok0, _ = dp.replicas_identical(all_models)
+    dp.counters(reset=True)
+    losses = {n: [] for n in ex.get_loss_names()}
+    ex.train_batch(losses)
+    cnt = dp.counters()
+    ok1, cs = dp.replicas_identical(all_models)
+    # different batches per rank (rank-offset data seed), yet identical replicas afterwards; 5 trainer steps, one collective per arena
+    full = dict(ok0=ok0, ok1=ok1, steps=cnt['steps'], collectives=cnt['collectives'], overlapped=cnt['overlapped'],
+                finite=all(np.isfinite(float(v)) for k in losses for v in losses[k]), n_gens=len(gens), checksum=cs[:4])
+    q.put((rank, dm_after.numpy(), [g.numpy() for g in gathered], float(h.history['loss'][0]), tiny_grad, seg_grad, seg_state, full))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -145,6 +160,13 @@ def test_dp_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    # the full executor iteration: replicas identical before and after, 5 trainer steps (generator + 2 D_Mask + D_Image1/2),
+    # one collective per generator arena + one per discriminator fit, the generator's all overlapped with its backward pass
+    for r in res:
+        f = r[7]
+        assert f['ok0'] and f['ok1'] and f['finite'], f
+        assert f['steps'] == 5 and f['collectives'] == f['n_gens'] + 4 and f['overlapped'] == f['n_gens'], f
+    assert res[0][7]['checksum'] == res[1][7]['checksum']
     # replicas identical after both steps
     assert np.array_equal(res[0][1], res[1][1]), 'D_Mask replicas diverged'
     for a, b in zip(res[0][2], res[1][2]):

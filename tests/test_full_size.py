@@ -217,7 +217,7 @@ def test_config2_generator_step_at_256_bs8_against_the_oracle():
     fp32 here: the fp64 run needs > 60 GB; tolerances as in test_dafnet_step.py, gradients against a fixed bar because the fp32
     oracle IS the noise floor)."""
     from tests.test_dafnet_step import _generator_step_check
-    _generator_step_check('film', H, True, 'cuda', B=B, oracle_dtype=torch.float32, out_tol=1e-3, grad_floor=0.15)
+    _generator_step_check('film', H, True, 'cuda', B=B, oracle_dtype=torch.float32, out_tol=1e-3, grad_floor=6e-2)
 
 
 def _fixed_batch_property_run(model, conf, d, ref_losses=None):

@@ -5,7 +5,10 @@ forcing) from identically seeded weights on identical batches and draws, evaluat
 stochastic-weight-averaged model (callbacks/swa.py: running mean of the weights, BatchNorm moving statistics included) -- on a
 fixed synthetic validation split of 256 paired slices.
 
-    python tools/dice_seeds.py <seed> <product|oracle> [iterations=500] [size=64] [batch=4] [lr=1e-3] [swa_from=350] [swa_every=10]
+    python tools/dice_seeds.py <seed> <product|oracle|standin> [iterations=500] [size=64] [batch=4] [lr=1e-3] [swa_from=350] [swa_every=10]
+        product: the HIP kernels on the GPU; oracle: oracle/ on the CPU; standin: the PRODUCT's host logic (graphs, trainers, pools,
+        caches) on tests/cpu_backend.py, i.e. torch-CPU arithmetic under the product's Python -- separates "host logic" from "kernel
+        numerics" without a GPU.  DICE_LABEL=<name> relabels the RESULT line (e.g. a second oracle realisation with ORACLE_THREADS=1)
     python tools/dice_seeds.py summary <log> [<log> ...]        # mean +- 95 % CI of (product - oracle) over the seeds
     DICE_CHECKS=10,25,50,100,200 python tools/dice_seeds.py ...  # also evaluate the LIVE model after these iterations (CHECK lines)
 
@@ -117,7 +120,8 @@ def main():
     wchecks = set(int(v) for v in os.environ.get('DICE_WCHECKS', '').split(',') if v)   # ... after which the weight norm is printed
     odt = torch.float32                                   # the oracle runs in fp32 here (CPU time); the product is fp32 too
     torch.set_num_threads(int(os.environ.get('ORACLE_THREADS', max(1, min(len(os.sched_getaffinity(0)), 16)))))
-    if side == 'oracle':                                  # no GPU: build the identically seeded model on the CPU stand-in to export weights
+    label = os.environ.get('DICE_LABEL', side)
+    if side in ('oracle', 'standin'):                     # no GPU: build the identically seeded model on the CPU stand-in (oracle: to export weights)
         from tests import cpu_backend as _cb
         _cb.install(); nn.set_default_device('cpu')
     else:
@@ -217,17 +221,17 @@ def main():
     t0 = time.time()
     for it in range(iters):
         d = batch()
-        if side == 'product':
+        if side in ('product', 'standin'):
             loss = product_step(d)
         else:
             loss = orc.train_batch(Hh.to_torch(d, odt), supervised=True)['supervised_Mask']
         if it >= swa_from and (it - swa_from) % swa_every == 0:
             swa_update()
         if it % 50 == 0 or it == iters - 1:
-            print('seed %d %s iter %4d seg loss %.4f (%.0f s)' % (seed, side, it, loss, time.time() - t0), flush=True)
+            print('seed %d %s iter %4d seg loss %.4f (%.0f s)' % (seed, label, it, loss, time.time() - t0), flush=True)
         if it + 1 in checks:
             c1, c2 = evaluate_live()
-            print('CHECK %d %s %d %.5f %.5f %.5f' % (seed, side, it + 1, c1, c2, 0.5 * (c1 + c2)), flush=True)
+            print('CHECK %d %s %d %.5f %.5f %.5f' % (seed, label, it + 1, c1, c2, 0.5 * (c1 + c2)), flush=True)
         if it + 1 in wchecks:
             # a well-conditioned trajectory observable: L2 norm and sum of the weights of the segmentation path (float64 on the host).
             # Kernels, gamma / beta and moving variances only: a convolution bias in front of a BatchNorm has an identically zero
@@ -239,11 +243,11 @@ def main():
             else:           # the same tensors under the oracle's names (the encoders' shared up-path counted once)
                 ws = [v.detach().double().cpu().numpy().ravel() for k, v in sorted(Hh.export_dafnet(model, torch.float32).items()) if keep(k)]
             w = np.concatenate(ws)
-            print('WCHECK %d %s %d %d %.12e %.12e' % (seed, side, it + 1, w.size, np.sqrt((w * w).sum()), w.sum()), flush=True)
+            print('WCHECK %d %s %d %d %.12e %.12e' % (seed, label, it + 1, w.size, np.sqrt((w * w).sum()), w.sum()), flush=True)
     if swa is None:
         return
     d1, d2 = evaluate_swa()
-    print('RESULT %d %s %.5f %.5f %.5f' % (seed, side, d1, d2, 0.5 * (d1 + d2)), flush=True)
+    print('RESULT %d %s %.5f %.5f %.5f' % (seed, label, d1, d2, 0.5 * (d1 + d2)), flush=True)
 
 
 if __name__ == '__main__':
