@@ -42,7 +42,11 @@ TFLOP_PER_PAIR = {('film', 256): 1.630, ('spade', 256): 2.871, ('mmsdnet', 256):
 
 _FAMILY = {1: 'conv_fast_kernel', 2: 'conv_fwd_kernel', 3: 'conv_direct_kernel', 4: 'conv_fast_batched_kernel',
            5: 'conv_dgrad_s2k4_smallc_kernel', 6: 'conv_wgrad_tr_kernel', 7: 'conv_wgrad_fast_kernel', 8: 'conv_wgrad_kernel',
-           9: 'conv_wgrad_c8_kernel'}
+           9: 'conv_wgrad_c8_kernel', 10: 'pw_reduce_kernel', 11: 'smallk_conv_kernel', 12: 'pw_reduce_wgrad_kernel',
+           13: 'smallk_wgrad_kernel'}
+HBM_BOUND_FAMILIES = ('pw_reduce_kernel', 'smallk_conv_kernel', 'pw_reduce_wgrad_kernel', 'smallk_wgrad_kernel', 'conv_direct_kernel',
+                      'conv_wgrad_c8_kernel', 'conv_dgrad_s2k4_smallc_kernel')
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
 
 
 def kernel_name(kid, prec):
@@ -69,6 +73,10 @@ def kernel_name(kid, prec):
         return 'conv_direct_kernel<8, 8, 3>'
     if fam == 5:
         return 'conv_dgrad_s2k4_smallc_kernel<%d>' % bm
+    if fam in (10, 12):             # <lanes per pixel, outputs, 16-byte vectors per lane>
+        return '%s<%d, %d, %d>' % (_FAMILY[fam], bm, bn, 2 if (bm, bn) == (8, 8) else 1)
+    if fam in (11, 13):             # <kernel size, input channels, lanes per pixel>
+        return '%s<%d, %d, %d>' % (_FAMILY[fam], bm // 20, bn, bm % 20)
     return _FAMILY.get(fam, 'kernel_%d' % kid)
 
 
@@ -499,6 +507,14 @@ def main():
         def entry(k, launches, label):
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
             avg = k['ms'] / k['launches']
+            if label.split('<')[0] in HBM_BOUND_FAMILIES:
+                # the small-channel layers are bandwidth kernels: algorithmic bytes (every input, weight and output element once)
+                # over the launch time against the HBM peak
+                gbs = k['bytes'] / (k['ms'] * 1e-3) / 1e9
+                return {'bound': 'hbm', 'kernel': label, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                        'traffic': None, 'algorithmic_bytes_per_launch': k['bytes'] / k['launches'],
+                        'flops_per_launch': k['flops'] / k['launches'], 'launches': launches, 'timed_launches': k['launches'],
+                        'avg_launch_ms': avg, 'gpu_ms_per_step': avg * launches / args.steps}
             return {'bound': 'mfma', 'kernel': label, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                     'traffic': None, 'algorithmic_bytes_per_launch': k['bytes'] / k['launches'],
                     'flops_per_launch': k['flops'] / k['launches'], 'launches': launches, 'timed_launches': k['launches'],
@@ -515,7 +531,7 @@ def main():
             line['roofline'] = dict(per_kernel[0], precision=prec_note,
                                     sampling='every %d-th convolution launch of the timed region bracketed by HIP events' % timer.stride,
                                     traffic_source=('profiles/r02_conv_traffic.json[%s]' % wkey) if per_kernel[0]['traffic'] else None)
-            line['roofline_kernels'] = [e for e in per_kernel if e['gpu_ms_per_step'] >= 0.5]
+            line['roofline_kernels'] = [e for e in per_kernel if e['gpu_ms_per_step'] >= 0.5 or e['bound'] == 'hbm']
         fam = {}
         for kind, label in (('conv_fwd_kernel', 'forward + data-gradient convolution launches (all template instances)'),
                             ('conv_wgrad_kernel', 'weight-gradient launches incl. the slab reduction (all template instances)')):

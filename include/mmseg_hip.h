@@ -167,6 +167,11 @@ int mmseg_bn_infer_fold(const float* gamma, const float* beta, const float* mov_
 int mmseg_bn_apply(const float* x, const float* scale, const float* shift, float* y, long M, int C, int relu, void* stream);
 int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean, const float* invstd,
                  float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu, int accumulate, void* stream);
+/* the same without the saved output y: the ReLU mask is recomputed from x with the forward pass's scale / shift (mmseg_bn_stats),
+ * bit-identical to the mask of mmseg_bn_apply's output -- 5 tensor passes over HBM instead of 7 */
+int mmseg_bn_bwd_x(const float* dy, const float* x, const float* scale, const float* shift, const float* gamma, const float* mean,
+                   const float* invstd, float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu,
+                   int accumulate, void* stream);
 /* Synchronised BatchNorm over data-parallel ranks (build-defined option conf.sync_bn; the reference is single device, SURVEY 8e iii):
  * the two halves of mmseg_bn_stats / mmseg_bn_bwd, the caller exchanging [2][C] floats in between (all-gather of (mean, biased
  * variance) in rank order; all-reduce(sum) of (sum g, sum g*xhat)).  stat2 / sums: [2][C]; gathered: [R][2][C]; coef: [3][C]. */

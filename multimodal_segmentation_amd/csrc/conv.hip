@@ -767,7 +767,9 @@ struct ConvBatch { ConvParams p[4]; int nblk[4]; };
 static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
 // which kernel template the last convolution entry point launched (mmseg_conv2d_last_kernel): family * 1000000 + 500000 * flag +
 // M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / 16-bit input of the fast kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
-// 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel
+// 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel,
+// 10 pw_reduce_kernel<LANES, COUT, VPL>, 12 pw_reduce_wgrad_kernel<...> (M tile field = LANES, N tile field = COUT);
+// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN)
 static int g_last_kernel = 0;
 #define MMSEG_SET_LAST(fam, bm, bn) (g_last_kernel = (fam) * 1000000 + (bm) * 1000 + (bn))
 template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false>
@@ -902,6 +904,60 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+#include "smallconv.hpp"
+
+// HBM-bound small-channel layers (smallconv.hpp): -1 = not one of them, otherwise the launch's return code
+static int smallconv_dispatch(const ConvParams& p, hipStream_t st) {
+    static const bool on = [] { const char* e = getenv("MMSEG_SMALLCONV"); return !(e && e[0] == '0'); }();
+    if (!on || p.io != 0 || p.C2 != 0 || p.ups || p.transposed || p.y2 != nullptr || p.w == nullptr || p.osh != 1 || p.osw != 1 || p.ooh != 0 ||
+        p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo || !aligned16(p.x1) || !aligned16(p.y) || !aligned16(p.w)) return -1;
+    const long M = p.M;
+    const bool one = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0;
+    // "reduce" type: wide input, <= 8 outputs
+    if (one) {
+#define PWR(LANES, COUT, VPL)                                                                                                         \
+        do {                                                                                                                           \
+            long nb = (M + 64 * (64 / LANES) - 1) / (64 * (64 / LANES));     /* >= 4 iterations per wave: the weight prologue */       \
+            if (nb > 2048) nb = 2048;                                                                                                  \
+            hipLaunchKernelGGL((pw_reduce_kernel<LANES, COUT, VPL>), dim3((unsigned)nb), dim3(256), 0, st, p.x1, p.w, p.bias, p.oscale, p.y, M, \
+                               p.act, p.alpha, g_conv_bf16);                                                                           \
+            MMSEG_SET_LAST(10, LANES, COUT);                                                                                           \
+            return MMSEG_CHECK_LAUNCH();                                                                                               \
+        } while (0)
+        if (p.C1 == 64 && p.Cout == 5) PWR(16, 5, 1);
+        if (p.C1 == 64 && p.Cout == 8) PWR(8, 8, 2);
+        if (p.C1 == 16 && p.Cout == 1) PWR(4, 1, 1);
+        if (p.C1 == 8 && p.Cout == 1) PWR(2, 1, 1);
+#undef PWR
+    }
+    // "expand" type: <= 16 gathered values per pixel, L = Cout / 4 lanes per pixel
+    const int L = p.Cout / 4;
+    if (p.Cout % 4 != 0 || (L != 2 && L != 4 && L != 16) || p.KH != p.KW || (p.bias && !aligned16(p.bias)) ||
+        (p.oscale && !aligned16(p.oscale))) return -1;
+#define SMK1(KS, CIN, LL)                                                                                                              \
+    do {                                                                                                                               \
+        long nb = (M * LL + 1023) / 1024;                                                                                              \
+        if (nb > 2048) nb = 2048;                                                                                                      \
+        hipLaunchKernelGGL((smallk_conv_kernel<KS, CIN, LL>), dim3((unsigned)nb), dim3(256), 0, st, p, (CIN % 4 == 0) ? g_conv_bf16 : 0); \
+        MMSEG_SET_LAST(11, KS * 20 + LL, CIN);                                                                                         \
+        return MMSEG_CHECK_LAUNCH();                                                                                                   \
+    } while (0)
+#define SMK(KS, CIN)                                                                                                                   \
+    do {                                                                                                                               \
+        if (L == 16) SMK1(KS, CIN, 16);                                                                                                \
+        if (L == 4) SMK1(KS, CIN, 4);                                                                                                  \
+        SMK1(KS, CIN, 2);                                                                                                              \
+    } while (0)
+    if (one && p.C1 == 1) SMK(1, 1);
+    if (one && p.C1 == 5) SMK(1, 5);
+    if (one && p.C1 == 8) SMK(1, 8);
+    if (p.KH == 3 && p.C1 == 1) SMK(3, 1);
+    if (p.KH == 4 && p.C1 == 1) SMK(4, 1);
+#undef SMK1
+#undef SMK
+    return -1;
+}
+
 // the quad-transposed epilogue stores 4 channels per lane: 16-byte (fp32) / 8-byte (16-bit) aligned output rows
 static int quad_epilogue_ok(const ConvParams& p) {
     static const bool on = [] { const char* e = getenv("MMSEG_QUAD_EPI"); return !(e && e[0] == '0'); }();
@@ -919,6 +975,10 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
                            p.x1, p.w, p.bias, p.y, p.B, p.H, p.W, 1, p.act, p.alpha);
         MMSEG_SET_LAST(3, 8, 8);
         return MMSEG_CHECK_LAUNCH();
+    }
+    {
+        const int rc = smallconv_dispatch(p, st);
+        if (rc >= 0) return rc;
     }
     const bool vec = (p.C1 % 4 == 0) && (p.C2 % 4 == 0) && aligned16(p.x1) && (p.C2 == 0 || aligned16(p.x2));
     const long tiles_big = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
@@ -2189,6 +2249,48 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
         MMSEG_SET_LAST(9, 8, 8);
         launch_slab_reduce(ws, tmp, dw, KN, nblk, accumulate, st);
         return MMSEG_CHECK_LAUNCH();
+    }
+    {
+        // HBM-bound small-channel layers (smallconv.hpp): per-block slabs, then the deterministic slab reduction
+        static const bool sc_on = [] { const char* e = getenv("MMSEG_SMALLCONV"); return !(e && e[0] == '0'); }();
+        const bool base = sc_on && io == 0 && C2 == 0 && !ups && aligned16(x1) && aligned16(dy) && KH == KW;
+        const bool one = KH == 1 && stride == 1 && pad_h == 0 && pad_w == 0;
+        long cap = wgrad_splits(p.M, p.K, Cout);                 // slabs the caller's workspace holds
+        if (cap > 1024) cap = 1024;
+        int launched = 0, nblk = 0;
+#define PWW(LANES, COUT, VPL)                                                                                                         \
+        do {                                                                                                                           \
+            long nb = (p.M + 256 * (64 / LANES) - 1) / (256 * (64 / LANES));                                                           \
+            nblk = (int)(nb < cap ? nb : cap);                                                                                         \
+            hipLaunchKernelGGL((pw_reduce_wgrad_kernel<LANES, COUT, VPL>), dim3(nblk), dim3(256),                                      \
+                               (size_t)(256 / LANES) * (4 * LANES * VPL) * COUT * sizeof(float), st, x1, dy, ws, (long)p.M,            \
+                               (COUT % 4 == 0) ? g_conv_bf16 : 0);                                                                      \
+            MMSEG_SET_LAST(12, LANES, COUT);                                                                                           \
+            launched = 1;                                                                                                              \
+        } while (0)
+        if (base && one && C1 == 64 && Cout == 5) PWW(16, 5, 1);
+        else if (base && one && C1 == 64 && Cout == 8) PWW(8, 8, 2);
+        else if (base && one && C1 == 16 && Cout == 1) PWW(4, 1, 1);
+        else if (base && one && C1 == 8 && Cout == 1) PWW(2, 1, 1);
+#undef PWW
+        const int L = Cout / 4;
+        if (!launched && base && C1 == 1 && (KH == 3 || KH == 4) && Cout % 4 == 0 && (L == 2 || L == 4 || L == 16)) {
+            long nb = ((long)p.M * L + 4095) / 4096;
+            nblk = (int)(nb < cap ? nb : cap);
+            const size_t shm = (size_t)4 * p.K * Cout * sizeof(float);
+#define SMW(KS, LL) hipLaunchKernelGGL((smallk_wgrad_kernel<KS, 1, LL>), dim3(nblk), dim3(256), shm, st, p, dy, ws)
+            if (KH == 3) { if (L == 16) SMW(3, 16); else if (L == 4) SMW(3, 4); else SMW(3, 2); }
+            else { if (L == 16) SMW(4, 16); else if (L == 4) SMW(4, 4); else SMW(4, 2); }
+#undef SMW
+            MMSEG_SET_LAST(13, KH * 20 + L, 1);
+            launched = 1;
+        }
+        if (launched) {
+            float* tmp2 = (nblk > 64) ? ws + (size_t)nblk * KN : nullptr;
+            if (wgrad_ws_floats(nblk, KN) > ws_floats) return (int)hipErrorInvalidValue;
+            launch_slab_reduce(ws, tmp2, dw, KN, nblk, accumulate, st);
+            return MMSEG_CHECK_LAUNCH();
+        }
     }
     int rc;
     if (tr && Cout > 64 && wgrad_tr_bkt(p.K, Cout) == 192) rc = launch_wgrad_tr<192, 128, 2, 2>(q, S, st);

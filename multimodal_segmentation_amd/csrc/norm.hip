@@ -20,7 +20,8 @@ static inline int norm_blocks(long M) {
 template <int MODE>
 __global__ void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
                                   const float* __restrict__ mean, const float* __restrict__ invstd,
-                                  float* __restrict__ part, long M, int C, long rows_per_block, int relu) {
+                                  float* __restrict__ part, long M, int C, long rows_per_block, int relu,
+                                  const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr) {
     __shared__ float sm[2 * 256];
     const int tid = threadIdx.x;
     const int cw = min(C, 256), rl = 256 / cw;
@@ -35,10 +36,13 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, const float* __re
                 for (long r = r0 + r_in; r < r1; r += rl) { const float d = x[r * C + c] - sh; s1 += d; s2 += d * d; }
             } else {
                 const float mu = mean[c], is = invstd[c];
+                const float sc = y ? 0.f : scale[c], sh = y ? 0.f : shift[c];
                 for (long r = r0 + r_in; r < r1; r += rl) {
                     float g = dy[r * C + c];
-                    if (relu && !(y[r * C + c] > 0.f)) g = 0.f;
-                    s1 += g; s2 += g * (x[r * C + c] - mu) * is;
+                    const float xv = x[r * C + c];
+                    // ReLU mask from the saved output, or recomputed from the input exactly as bn_apply_kernel computed the output
+                    if (relu && !((y ? y[r * C + c] : fmaf(xv, sc, sh)) > 0.f)) g = 0.f;
+                    s1 += g; s2 += g * (xv - mu) * is;
                 }
             }
         }
@@ -61,7 +65,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ part,
-                                                            long M, int C, long rows_per_block, int relu) {
+                                                            long M, int C, long rows_per_block, int relu,
+                                                            const float* __restrict__ scale = nullptr,
+                                                            const float* __restrict__ shift = nullptr) {
     __shared__ f32x4 sm[2][16][16];
     const int tid = threadIdx.x, c4 = tid & 15, rl = tid >> 4;
     const int C4 = C >> 2;
@@ -80,15 +86,29 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
         const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[col], is = reinterpret_cast<const f32x4*>(invstd)[col];
         const f32x4* DY = reinterpret_cast<const f32x4*>(dy);
         const f32x4* Y = reinterpret_cast<const f32x4*>(y);
+        if (relu && y == nullptr) {
+            // ReLU mask recomputed from the input with bn_apply_kernel's own expression (same fused multiply-add, same bits):
+            // one tensor less to read
+            const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[col], sh = reinterpret_cast<const f32x4*>(shift)[col];
 #pragma unroll 4
-        for (long r = r0 + rl; r < r1; r += 16) {
-            f32x4 g = DY[r * C4 + col];
-            if (relu) {
-                const f32x4 o = Y[r * C4 + col];
+            for (long r = r0 + rl; r < r1; r += 16) {
+                f32x4 g = DY[r * C4 + col];
+                const f32x4 xv = X[r * C4 + col];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+                for (int e = 0; e < 4; ++e) g[e] = fmaf(xv[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+                s1 += g; s2 += g * (xv - mu) * is;
             }
-            s1 += g; s2 += g * (X[r * C4 + col] - mu) * is;
+        } else {
+#pragma unroll 4
+            for (long r = r0 + rl; r < r1; r += 16) {
+                f32x4 g = DY[r * C4 + col];
+                if (relu) {
+                    const f32x4 o = Y[r * C4 + col];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+                }
+                s1 += g; s2 += g * (X[r * C4 + col] - mu) * is;
+            }
         }
     }
     sm[0][rl][c4] = s1; sm[1][rl][c4] = s2;
@@ -241,7 +261,10 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     const f32x4* T = reinterpret_cast<const f32x4*>(shift);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = i % C4;
-        f32x4 v = reinterpret_cast<const f32x4*>(x)[i] * S[c] + T[c];
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i], sc = S[c], sh = T[c];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(xv[e], sc[e], sh[e]);      // (the backward pass recomputes the ReLU mask with this expression)
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
@@ -268,19 +291,27 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ part, const float*
 }
 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
-                                    const float* __restrict__ coef, float* __restrict__ dx, long n4, int C4, int relu) {
+                                    const float* __restrict__ coef, float* __restrict__ dx, long n4, int C4, int relu,
+                                    const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr) {
     const f32x4* A = reinterpret_cast<const f32x4*>(coef);
     const f32x4* Bc = A + C4;
     const f32x4* Cc = A + 2 * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = i % C4;
         f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
         if (relu) {
-            const f32x4 o = reinterpret_cast<const f32x4*>(y)[i];
+            if (y) {
+                const f32x4 o = reinterpret_cast<const f32x4*>(y)[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+                for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+            } else {
+                const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c], sh = reinterpret_cast<const f32x4*>(shift)[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = fmaf(xv[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+            }
         }
-        reinterpret_cast<f32x4*>(dx)[i] = A[c] * g + Bc[c] * reinterpret_cast<const f32x4*>(x)[i] + Cc[c];
+        reinterpret_cast<f32x4*>(dx)[i] = A[c] * g + Bc[c] * xv + Cc[c];
     }
 }
 
@@ -529,6 +560,29 @@ int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* g
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M, accumulate);
     const long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y, x, (const float*)coef, dx, n4, C / 4, relu);
+    return MMSEG_CHECK_LAUNCH();
+}
+// The same without the saved output: the ReLU mask is recomputed from x with the forward pass's scale / shift (mmseg_bn_stats
+// outputs; bit-identical to the mask of mmseg_bn_apply's output) -- 5 tensor passes instead of 7
+int mmseg_bn_bwd_x(const float* dy, const float* x, const float* scale, const float* shift, const float* gamma, const float* mean,
+                   const float* invstd, float* dx, float* dgamma, float* dbeta, float* coef, float* ws, long M, int C, int relu,
+                   int accumulate, void* stream) {
+    if (C & 3) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const float* none = nullptr;
+    int nblk;
+    if ((C & 63) == 0) {
+        nblk = v4_row_blocks(M, C);
+        const long rpb = (M + nblk - 1) / nblk;
+        hipLaunchKernelGGL(bn_partial_v4_kernel<1>, dim3(nblk, C / 64), dim3(256), 0, st, x, dy, none, mean, invstd, ws, M, C, rpb, relu, scale, shift);
+    } else {
+        nblk = norm_blocks(M);
+        const long rpb = (M + nblk - 1) / nblk;
+        hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, none, mean, invstd, ws, M, C, rpb, relu, scale, shift);
+    }
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M, accumulate);
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, none, x, (const float*)coef, dx, n4, C / 4, relu, scale, shift);
     return MMSEG_CHECK_LAUNCH();
 }
 

@@ -82,7 +82,7 @@ class GraphedCall(object):
         for b, x in zip(st.s_in, xs):
             b.copy_(x)
         for d in st.draws:
-            self._fill(d.buf, d.fn())
+            FitGraph._fill(d.buf, d.fn())
         if st.graph is None:
             ops.bump_weight_version()                 # every cached weight image / BatchNorm fold is recomputed INSIDE the recording
             st.mode, st.draw_i = 'capture', 0
@@ -165,7 +165,7 @@ class FitGraph(object):
             if self._is_tensorlike(x):
                 self._fill(b, x)
         for d in self.draws:                          # this step's host draws, in the order the step asks for them
-            self._fill(d.buf, d.fn())
+            FitGraph._fill(d.buf, d.fn())
         lr_dev = t.optimizer.begin_device_step(dev)   # iteration count + 1, lr_t of this step into the device scalar
         if self.graph is None:
             from . import ops as _ops

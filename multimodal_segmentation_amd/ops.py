@@ -438,7 +438,7 @@ class _BatchNormTrain(torch.autograd.Function):
         N.call('mmseg_bn_apply', x, stats[2], stats[3], y, M, C, int(relu))
         ctx.relu = bool(relu)
         ctx.gamma, ctx.ggrad, ctx.bgrad = gamma, ggrad, bgrad
-        ctx.save_for_backward(x, y if relu else None, stats)
+        ctx.save_for_backward(x, y if (relu and ctx.sync) else None, stats)
         return y
 
     @staticmethod
@@ -470,13 +470,16 @@ class _BatchNormTrain(torch.autograd.Function):
             N.call('mmseg_bn_bwd_apply', dy, y, x, coef, dx, M, C, int(ctx.relu))
             _grad_done(ctx.ggrad, ctx.bgrad)
             return (dx,) + (None,) * 9
+        # (the ReLU mask is recomputed from x with the forward pass's scale / shift: the saved output is not read again)
         if ctx.ggrad is not None and ctx.bgrad is not None:
             # the final reduction adds dgamma / dbeta straight into the gradient-arena views
-            N.call('mmseg_bn_bwd', dy, y, x, ctx.gamma, stats[0], stats[1], dx, ctx.ggrad, ctx.bgrad, coef, ws, M, C, int(ctx.relu), 1)
+            N.call('mmseg_bn_bwd_x', dy, x, stats[2], stats[3], ctx.gamma, stats[0], stats[1], dx, ctx.ggrad, ctx.bgrad, coef, ws, M, C,
+                   int(ctx.relu), 1)
         else:
             tmp = _ws('bn_dgb', 2 * C, x.device)
             dgamma, dbeta = tmp[:C], tmp[C:2 * C]
-            N.call('mmseg_bn_bwd', dy, y, x, ctx.gamma, stats[0], stats[1], dx, dgamma, dbeta, coef, ws, M, C, int(ctx.relu), 0)
+            N.call('mmseg_bn_bwd_x', dy, x, stats[2], stats[3], ctx.gamma, stats[0], stats[1], dx, dgamma, dbeta, coef, ws, M, C,
+                   int(ctx.relu), 0)
             if ctx.ggrad is not None:
                 _accumulate(ctx.ggrad, dgamma)
             if ctx.bgrad is not None:

@@ -372,6 +372,11 @@ def bn_bwd(dy, y, x, gamma, mean, invstd, dx, dgamma, dbeta, coef, ws, M, C, rel
     dx.copy_((gamma * invstd * (g - db / M - xh * dg / M)).reshape(dx.shape)); return 0
 
 
+def bn_bwd_x(dy, x, scale, shift, gamma, mean, invstd, dx, dgamma, dbeta, coef, ws, M, C, relu, accumulate):
+    y = (x.reshape(M, C) * scale + shift).reshape(x.shape)          # the forward pass's pre-ReLU output (bn_apply's own expression)
+    return bn_bwd(dy, y, x, gamma, mean, invstd, dx, dgamma, dbeta, coef, ws, M, C, relu, accumulate)
+
+
 def in_workspace_floats(B):
     return 1
 

@@ -45,16 +45,25 @@ def test_conv_fwd_16bit_io(B, H, C1, C2, Cout, ups, act, mode):
         y = torch.empty(B, H, H, Cout, device=DEV, dtype=mode if out16 else torch.float32)
         io = 1 | (2 if C2 else 0) | (4 if out16 else 0)
         N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, p, p, ups, 0, act, 0.0, 0, io)
+        if Cout == 8 and k == 1:
+            # the fp32-storage call of this 1x1 head runs on the bandwidth kernel of csrc/smallconv.hpp (round 3), the 16-bit-input call on
+            # the MFMA kernel: same rounded operands and fp32 accumulation, another summation order
+            ref = y32.to(mode).float() if out16 else y32
+            assert (y.float() - ref).abs().max() <= (2.0 ** -7 if out16 else 1e-5) * float(ref.abs().max()), 'out16=%s' % out16
+            continue
         assert torch.equal(y, y32.to(mode) if out16 else y32), 'out16=%s' % out16
     # mixed: fp32 inputs, 16-bit output
     y = torch.empty(B, H, H, Cout, device=DEV, dtype=mode)
     N.call('mmseg_conv2d_fwd_t', x1.float(), x2.float() if C2 else None, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, p, p, ups,
            0, act, 0.0, 0, 4)
-    assert torch.equal(y, y32.to(mode))
+    if Cout == 8 and k == 1:
+        assert (y.float() - y32).abs().max() <= 2.0 ** -7 * float(y32.abs().max())
+    else:
+        assert torch.equal(y, y32.to(mode))
 
 
 def test_generic_kernel_writes_16bit_and_refuses_16bit_inputs(mode):
-    B, H, Cin, Cout = 2, 20, 1, 64
+    B, H, Cin, Cout = 2, 20, 3, 64         # (3 input channels: the generic implicit-GEMM kernel, not a small-channel bandwidth kernel)
     x = rnd(B, H, H, Cin, seed=5).to(DEV)
     w = (rnd(3, 3, Cin, Cout, seed=6) * 0.2).to(DEV)
     y32 = torch.empty(B, H, H, Cout, device=DEV)

@@ -115,6 +115,15 @@ CONV_CASES = [
     (2, 20, 21, 8, 0, 64, 3, 1, 'valid', 'leaky', False),      # few input channels, 'valid': data gradient = 1x1 GEMM over the taps + tap sum
     (2, 16, 20, 4, 0, 32, 3, 1, 'same', None, False),          # Cin = 4 through the same path
     (1, 24, 24, 16, 0, 128, 3, 1, 'same', 'relu', False),      # Cin = 16: 144 GEMM columns
+    # round 3: the HBM-bound small-channel kernels (csrc/smallconv.hpp), pixel counts that do not fill the last wave / block
+    (3, 17, 19, 64, 0, 5, 1, 1, 'same', None, False),          # segmentor head: pw_reduce<16, 5> + its wgrad; dgrad = smallk<1, 5>
+    (3, 17, 19, 64, 0, 8, 1, 1, 'same', None, False),          # anatomy head: pw_reduce<16, 8>; dgrad = smallk<1, 8>
+    (5, 13, 11, 8, 0, 1, 1, 1, 'same', 'tanh', False),         # FiLM decoder head: pw_reduce<2, 1>; dgrad = smallk<1, 1> (Cout 8)
+    (3, 15, 9, 16, 0, 1, 1, 1, 'same', 'tanh', False),         # SPADE decoder head: pw_reduce<4, 1>
+    (3, 17, 19, 1, 0, 64, 3, 1, 'same', 'relu', False),        # UNet d_l0.a: smallk<3, 1> forward + weight gradient
+    (2, 37, 41, 1, 0, 64, 4, 2, 'valid', 'leaky', False),      # D_Image first layer: smallk<4, 1>
+    (2, 19, 23, 1, 0, 16, 3, 1, 'same', None, False),          # 4 lanes per pixel
+    (1, 70, 70, 64, 0, 5, 1, 1, 'same', None, False),          # more pixels than one pass of the grid
 ]
 
 
@@ -400,7 +409,7 @@ def _bf16(t, dt=torch.bfloat16):
     (2, 16, 16, 64, 0, 64, 3, 1, 'same', False), (2, 32, 32, 128, 0, 128, 3, 1, 'same', False),
     (2, 16, 16, 64, 64, 64, 3, 1, 'same', False), (2, 16, 16, 128, 0, 64, 3, 1, 'same', True),
     (2, 8, 8, 256, 0, 512, 3, 1, 'same', False), (2, 16, 16, 64, 0, 128, 4, 2, 'valid', False),
-    (3, 24, 24, 64, 0, 8, 1, 1, 'same', False)])
+    (3, 24, 24, 64, 0, 8, 1, 1, 'same', False), (3, 17, 19, 64, 0, 5, 1, 1, 'same', False), (3, 17, 19, 8, 0, 1, 1, 1, 'same', False)])
 def test_conv2d_bf16_precision(B, H, W, Cin, C2, Cout, k, stride, padding, ups, mode):
     """mmseg_set_conv_precision(1): forward and data gradient == the fp64 oracle on bf16-rounded operands (the products are
     then exact, only the fp32 accumulation differs); the same for the weight gradient."""
@@ -442,7 +451,8 @@ def test_conv2d_bf16_precision(B, H, W, Cin, C2, Cout, k, stride, padding, ups, 
     if C2:
         _close(xp2.grad, gx[1], 'bf16 dgrad x2', 4e-4)
     # weight gradient (fast path: channel counts divisible by 4): input patches and incoming gradient rounded to bf16
-    gw = torch.autograd.grad(O.conv2d(_bf16(xin.detach()), wr, None, stride=stride, padding=padding), wr, _bf16(cot))[0]
+    rw = _bf16 if ((Cin + C2) % 4 == 0 and Cout % 4 == 0) else (lambda t: t.double())      # other shapes: fp32 weight-gradient kernels
+    gw = torch.autograd.grad(O.conv2d(rw(xin.detach()), wr, None, stride=stride, padding=padding), wr, rw(cot))[0]
     _close(wg, gw, 'bf16 wgrad', 4e-4)
     # and the rounding is really happening: the result differs from the unrounded oracle by more than fp32 noise
     y32 = O.conv2d(xin.detach(), D(w), D(b), stride=stride, padding=padding)
