@@ -908,13 +908,14 @@ static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 
 // HBM-bound small-channel layers (smallconv.hpp): -1 = not one of them, otherwise the launch's return code
 static int smallconv_dispatch(const ConvParams& p, hipStream_t st) {
-    static const bool on = [] { const char* e = getenv("MMSEG_SMALLCONV"); return !(e && e[0] == '0'); }();
+    static const int mask = [] { const char* e = getenv("MMSEG_SMALLCONV"); return e ? atoi(e) : 15; }();     // A/B: 1 reduce fwd, 2 expand fwd
+    const bool on = mask != 0;
     if (!on || p.io != 0 || p.C2 != 0 || p.ups || p.transposed || p.y2 != nullptr || p.w == nullptr || p.osh != 1 || p.osw != 1 || p.ooh != 0 ||
         p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo || !aligned16(p.x1) || !aligned16(p.y) || !aligned16(p.w)) return -1;
     const long M = p.M;
     const bool one = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0;
     // "reduce" type: wide input, <= 8 outputs
-    if (one) {
+    if (one && (mask & 1)) {
 #define PWR(LANES, COUT, VPL)                                                                                                         \
         do {                                                                                                                           \
             long nb = (M + 64 * (64 / LANES) - 1) / (64 * (64 / LANES));     /* >= 4 iterations per wave: the weight prologue */       \
@@ -932,6 +933,9 @@ static int smallconv_dispatch(const ConvParams& p, hipStream_t st) {
     }
     // "expand" type: <= 16 gathered values per pixel, L = Cout / 4 lanes per pixel
     const int L = p.Cout / 4;
+    if (!(mask & 2)) return -1;
+    static const int only_ks = [] { const char* e = getenv("MMSEG_SMALLCONV_KS"); return e ? atoi(e) : 0; }();
+    if (only_ks && p.KH != only_ks) return -1;
     if (p.Cout % 4 != 0 || (L != 2 && L != 4 && L != 16) || p.KH != p.KW || (p.bias && !aligned16(p.bias)) ||
         (p.oscale && !aligned16(p.oscale))) return -1;
 #define SMK1(KS, CIN, LL)                                                                                                              \
@@ -2252,8 +2256,8 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
     }
     {
         // HBM-bound small-channel layers (smallconv.hpp): per-block slabs, then the deterministic slab reduction
-        static const bool sc_on = [] { const char* e = getenv("MMSEG_SMALLCONV"); return !(e && e[0] == '0'); }();
-        const bool base = sc_on && io == 0 && C2 == 0 && !ups && aligned16(x1) && aligned16(dy) && KH == KW;
+        static const int sc_mask = [] { const char* e = getenv("MMSEG_SMALLCONV"); return e ? atoi(e) : 15; }();   // 4 reduce wgrad, 8 expand wgrad
+        const bool base = io == 0 && C2 == 0 && !ups && aligned16(x1) && aligned16(dy) && KH == KW;
         const bool one = KH == 1 && stride == 1 && pad_h == 0 && pad_w == 0;
         long cap = wgrad_splits(p.M, p.K, Cout);                 // slabs the caller's workspace holds
         if (cap > 1024) cap = 1024;
@@ -2268,13 +2272,14 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
             MMSEG_SET_LAST(12, LANES, COUT);                                                                                           \
             launched = 1;                                                                                                              \
         } while (0)
-        if (base && one && C1 == 64 && Cout == 5) PWW(16, 5, 1);
+        if (!(sc_mask & 4)) {}
+        else if (base && one && C1 == 64 && Cout == 5) PWW(16, 5, 1);
         else if (base && one && C1 == 64 && Cout == 8) PWW(8, 8, 2);
         else if (base && one && C1 == 16 && Cout == 1) PWW(4, 1, 1);
         else if (base && one && C1 == 8 && Cout == 1) PWW(2, 1, 1);
 #undef PWW
         const int L = Cout / 4;
-        if (!launched && base && C1 == 1 && (KH == 3 || KH == 4) && Cout % 4 == 0 && (L == 2 || L == 4 || L == 16)) {
+        if (!launched && (sc_mask & 8) && base && C1 == 1 && (KH == 3 || KH == 4) && Cout % 4 == 0 && (L == 2 || L == 4 || L == 16)) {
             long nb = ((long)p.M * L + 4095) / 4096;
             nblk = (int)(nb < cap ? nb : cap);
             const size_t shm = (size_t)4 * p.K * Cout * sizeof(float);
