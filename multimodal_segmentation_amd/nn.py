@@ -311,7 +311,7 @@ def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, ups
     b = m.params.get(name + '/bias')
     return ops.conv2d(x, w.data, b.data if b is not None else None, stride, padding, act, alpha, x2, upsample,
                       wgrad=w.g(), bgrad=b.g() if (b is not None and bias_grad) else None, anchor=anchor(x.device),
-                      wkey=id(w), out_dtype=out_dtype)
+                      wkey=(id(w), id(w.owner)), out_dtype=out_dtype)
 
 
 def dense(m, name, x, act=None, alpha=0.0):
@@ -346,7 +346,7 @@ def conv_bn(m, cname, bname, x, training, relu=False, x2=None, upsample=False, y
         return bn(m, bname, l, training, relu=relu, out_dtype=bn_dt)
     return ops.conv2d_bn_infer(x, w.data, b.data if b is not None else None, m.params[bname + '/gamma'].data,
                                m.params[bname + '/beta'].data, m.params[bname + '/moving_mean'].data,
-                               m.params[bname + '/moving_variance'].data, relu=relu, x2=x2, upsample=upsample, wkey=id(w),
+                               m.params[bname + '/moving_variance'].data, relu=relu, x2=x2, upsample=upsample, wkey=(id(w), id(w.owner)),
                                out_dtype=bn_dt)
 
 
@@ -408,7 +408,7 @@ class Adam(object):
             if st is None:
                 st = (ops.fill_(torch.empty_like(m.arena), 0.0), ops.fill_(torch.empty_like(m.arena), 0.0))
                 self.state[id(m)] = st
-            ops.adam_step(m.arena, m.grad_arena, st[0], st[1], lr_t, self.beta_1, self.beta_2, self.epsilon)
+            ops.adam_step(m.arena, m.grad_arena, st[0], st[1], lr_t, self.beta_1, self.beta_2, self.epsilon, owner=id(m))
 
 
 class History(object):

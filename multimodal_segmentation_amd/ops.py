@@ -115,10 +115,27 @@ _bn_state_version = [0]      # bumped whenever BatchNorm moving statistics may h
 _bnfold_cache = {}
 
 
-def bump_weight_version():
-    """Invalidate the cached weight re-layouts (called whenever weights change: optimiser step, set_weights)."""
-    _weight_version[0] += 1
+_owner_version = {}          # id(nn.Model) -> version of that model's weights (bumped by its optimiser steps only)
+
+
+def bump_weight_version(owner=None):
+    """Invalidate the cached weight re-layouts (called whenever weights change: optimiser step, set_weights).  `owner` = id of the
+    nn.Model whose arena changed: only the images of ITS parameters become stale -- a discriminator's Adam step no longer makes the
+    generator's ~100 forward images stale (they were re-laid out three times per iteration: after the generator step and again
+    after the mask- and image-discriminator steps).  Without `owner` everything is invalidated (set_weights, precision switch,
+    graph capture, broadcast)."""
+    if owner is None:
+        _weight_version[0] += 1
+    else:
+        _owner_version[owner] = _owner_version.get(owner, 0) + 1
     _bn_state_version[0] += 1
+
+
+def _wver(wkey):
+    """version stamp of a cached image: (global version, version of the owning model); wkey = (id(param), id(owner model))"""
+    if isinstance(wkey, tuple):
+        return (_weight_version[0], _owner_version.get(wkey[1], 0))
+    return (_weight_version[0], 0)
 
 
 def _wprep(w, KH, KW, Cin, Cout, mode, wkey=None):
@@ -131,11 +148,11 @@ def _wprep(w, KH, KW, Cin, Cout, mode, wkey=None):
         return out
     key = (wkey, w.data_ptr(), mode, _sid(w.device))
     ent = _wprep_cache.get(key)
-    if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == w.numel():
+    if ent is not None and ent[0] == _wver(wkey) and ent[1].numel() == w.numel():
         return ent[1]
     out = ent[1] if (ent is not None and ent[1].numel() == w.numel()) else torch.empty(w.numel(), dtype=torch.float32, device=w.device)
     N.call('mmseg_conv2d_wprep', w, out, KH, KW, Cin, Cout, mode)
-    _wprep_cache[key] = (_weight_version[0], out)
+    _wprep_cache[key] = (_wver(wkey), out)
     return out
 
 
@@ -144,7 +161,7 @@ def _wprep_col8(w, Cout, wkey=None):
     mmseg_im2col8_t: [72][Cout] + 24 zero rows -> [Cout][96]; cached per weight version like _wprep"""
     key = (wkey, w.data_ptr(), 'col8', _sid(w.device))
     ent = _wprep_cache.get(key) if wkey is not None else None
-    if ent is not None and ent[0] == _weight_version[0]:
+    if ent is not None and ent[0] == _wver(wkey):
         return ent[1]
     if ent is not None:
         pad, out = ent[2], ent[1]
@@ -154,7 +171,7 @@ def _wprep_col8(w, Cout, wkey=None):
     pad[:72 * Cout].copy_(w.reshape(-1))
     N.call('mmseg_conv2d_wprep', pad, out, 1, 1, 96, Cout, 0)
     if wkey is not None:
-        _wprep_cache[key] = (_weight_version[0], out, pad)
+        _wprep_cache[key] = (_wver(wkey), out, pad)
     return out
 
 
@@ -165,7 +182,7 @@ def _wprep_parity_all(w, KH, KW, Cin, Cout, stride, taps, wkey=None):
     n = sum(sizes)
     key = (wkey, w.data_ptr(), 'parity_all', stride, _sid(w.device))
     ent = _wprep_cache.get(key) if wkey is not None else None
-    if ent is not None and ent[0] == _weight_version[0] and ent[1].numel() == n:
+    if ent is not None and ent[0] == _wver(wkey) and ent[1].numel() == n:
         return ent[1]
     if wkey is None:
         out = _ws('wprep_parity_all', n, w.device)[:n]
@@ -179,7 +196,7 @@ def _wprep_parity_all(w, KH, KW, Cin, Cout, stride, taps, wkey=None):
                 N.call('mmseg_conv2d_wprep_parity', w, out[off:off + sz], KH, KW, Cin, Cout, stride, qh, qw)
             off += sz
     if wkey is not None:
-        _wprep_cache[key] = (_weight_version[0], out)
+        _wprep_cache[key] = (_wver(wkey), out)
     return out
 
 
@@ -369,13 +386,13 @@ def conv2d_bn_infer(x, w, cbias, gamma, beta, mov_mean, mov_var, relu=False, x2=
     # encoder layer four times per iteration with the same parameters)
     key = (wkey, gamma.data_ptr(), 'bnfold', _sid(gamma.device))
     ent = _bnfold_cache.get(key) if wkey is not None else None
-    if ent is not None and ent[0] == (_weight_version[0], _bn_state_version[0]):
+    if ent is not None and ent[0] == (_wver(wkey), _bn_state_version[0]):
         ss = ent[1]
     else:
         ss = ent[1] if ent is not None else _new((2, Cout), x1)
         N.call('mmseg_bn_infer_fold', gamma, beta, mov_mean, mov_var, cbias, ss[0], ss[1], Cout, BN_EPS)
         if wkey is not None:
-            _bnfold_cache[key] = ((_weight_version[0], _bn_state_version[0]), ss)
+            _bnfold_cache[key] = ((_wver(wkey), _bn_state_version[0]), ss)
     y = _new((B, Ho, Wo, Cout), x1, out_dtype)
     wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
     io = (1 if _h(x1) else 0) | (2 if _h(x2) else 0) | (4 if _h(y) else 0)
@@ -1137,14 +1154,15 @@ def spectral_reg_grad(w, sgn, scale=1.0):
     return dw
 
 
-def adam_step(p, g, m, v, lr_t, beta_1=0.9, beta_2=0.999, eps=1e-7):
-    """Keras 2.1.6 Adam over flat arenas (p, g, m, v: 1-D views of equal length)."""
+def adam_step(p, g, m, v, lr_t, beta_1=0.9, beta_2=0.999, eps=1e-7, owner=None):
+    """Keras 2.1.6 Adam over flat arenas (p, g, m, v: 1-D views of equal length).  `owner`: id of the nn.Model that owns the arena
+    (its cached weight images become stale; None: all of them)."""
     assert p.numel() == g.numel() == m.numel() == v.numel()
     if isinstance(lr_t, torch.Tensor):       # a device scalar: the launch stays valid when replayed from a captured graph
         N.call('mmseg_adam_p', p, g, m, v, p.numel(), lr_t, float(beta_1), float(beta_2), float(eps))
     else:
         N.call('mmseg_adam', p, g, m, v, p.numel(), float(lr_t), float(beta_1), float(beta_2), float(eps))
-    bump_weight_version()
+    bump_weight_version(owner)
 
 
 def fill_(t, value):
