@@ -211,6 +211,18 @@ int mmseg_instnorm_spade_fwd(const float* x, const float* gamma, const float* be
 int mmseg_instnorm_spade_bwd(const float* dy, const float* x, const float* stat, const float* gamma, const float* beta, float* dx,
                              float* dgamma, float* dbeta, float* dxn, float* ws, int B, long per_sample, float eps, float act_alpha,
                              void* stream);
+/* The same with gamma and beta as the two halves of ONE tensor gb [B*H*W][2C] (gamma = channels [0, C), beta = [C, 2C)) -- the
+ * output of a SPADE unit's gamma and beta convolutions run as one convolution (layers/spade.py:30-33 of the reference computes
+ * Conv2D(f)(a) twice on the same 128-channel tensor); dgb has the layout of gb.  per_sample = H*W*C, C % 4 == 0. */
+int mmseg_instnorm_spade_fwd_gb(const float* x, const float* gb, float* y, float* stat, float* ws, int B, long per_sample, int C, float eps,
+                                float act_alpha, void* stream);
+int mmseg_instnorm_spade_bwd_gb(const float* dy, const float* x, const float* stat, const float* gb, float* dx, float* dgb, float* dxn,
+                                float* ws, int B, long per_sample, int C, float eps, float act_alpha, void* stream);
+/* out[m] = (a[m] | b[m]) for M rows of Ca and Cb floats; da[m] += src[m][0:Ca], db[m] += src[m][Ca:]: the fused operand of two
+ * convolutions that share their input, and its gradient back into the two parameters */
+int mmseg_concat_cols(const float* a, const float* b, float* out, long M, int Ca, int Cb, void* stream);
+int mmseg_split_cols_acc(const float* src, float* da, float* db, long M, int Ca, int Cb, void* stream);
+
 
 /* ---- keras Dense for rows <= 32 (csrc/dense.hip) ----------------------------------------------------- */
 long mmseg_dense_workspace_floats(int R, int K, int N);

@@ -432,6 +432,71 @@ __global__ void in_bwd_apply_kernel(const float* __restrict__ dxn, const float* 
     (void)n;
 }
 
+// ---- the same with gamma and beta as the two halves of ONE tensor gb [B*H*W][2C] (gamma = channels [0, C), beta = [C, 2C)): the
+//      output of the fused gamma + beta convolution of a SPADE unit (ops.conv2d_pair).  16-byte accesses; C % 4 == 0. ----
+__global__ void in_apply_gb_kernel(const float* __restrict__ x, const float* __restrict__ stat, const float* __restrict__ gb,
+                                   float* __restrict__ y, long per_sample, int C4, float act_alpha) {
+    const int b = blockIdx.y;
+    const float mu = stat[2 * b], rs = stat[2 * b + 1];
+    const long n4 = per_sample >> 2;
+    const size_t off4 = (size_t)b * n4;
+    const f32x4* X = reinterpret_cast<const f32x4*>(x) + off4;
+    const f32x4* GB = reinterpret_cast<const f32x4*>(gb) + 2 * off4;
+    f32x4* Y = reinterpret_cast<f32x4*>(y) + off4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / C4;
+        const int c4 = (int)(i - pix * C4);
+        const f32x4 ga = GB[pix * 2 * C4 + c4], be = GB[pix * 2 * C4 + C4 + c4];
+        f32x4 v = (X[i] - mu) * rs;
+        v = v * (ga + 1.f) + be;
+        if (act_alpha >= 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * act_alpha;
+        }
+        Y[i] = v;
+    }
+}
+// pass 1 of the backward: dgb (dgamma | dbeta), dxn and the per-sample sums; expressions as in_bwd_partial_kernel
+__global__ void in_bwd_partial_gb_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stat,
+                                         const float* __restrict__ gb, float* __restrict__ dgb, float* __restrict__ dxn_out,
+                                         float* __restrict__ part, long per_sample, int nchunk, int C4, float act_alpha) {
+    __shared__ float red[17];
+    const int b = blockIdx.y;
+    const long n4 = per_sample >> 2;
+    const size_t off4 = (size_t)b * n4;
+    const float mu = stat[2 * b], rs = stat[2 * b + 1];
+    const long per = (n4 + nchunk - 1) / nchunk;
+    const long i0 = (long)blockIdx.x * per, i1 = min(n4, i0 + per);
+    const f32x4* X = reinterpret_cast<const f32x4*>(x) + off4;
+    const f32x4* DY = reinterpret_cast<const f32x4*>(dy) + off4;
+    const f32x4* GB = reinterpret_cast<const f32x4*>(gb) + 2 * off4;
+    f32x4* DGB = reinterpret_cast<f32x4*>(dgb) + 2 * off4;
+    f32x4* DXN = reinterpret_cast<f32x4*>(dxn_out) + off4;
+    float s1 = 0.f, s2 = 0.f;
+    for (long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const long pix = i / C4;
+        const int c4 = (int)(i - pix * C4);
+        const f32x4 xn = (X[i] - mu) * rs;
+        f32x4 g = DY[i];
+        const f32x4 ga = GB[pix * 2 * C4 + c4], be = GB[pix * 2 * C4 + C4 + c4];
+        f32x4 dxn, dga;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = xn[e] * (1.f + ga[e]) + be[e];
+            if (act_alpha >= 0.f && u < 0.f) g[e] *= act_alpha;
+            dga[e] = g[e] * xn[e];
+            dxn[e] = g[e] * (1.f + ga[e]);
+            s1 += dxn[e]; s2 += dxn[e] * xn[e];
+        }
+        DGB[pix * 2 * C4 + c4] = dga;
+        DGB[pix * 2 * C4 + C4 + c4] = g;
+        DXN[i] = dxn;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { part[((size_t)b * nchunk + blockIdx.x) * 2] = s1; part[((size_t)b * nchunk + blockIdx.x) * 2 + 1] = s2; }
+}
+
 // row blocks of the float4 fast path: ~1024 blocks in total, at most 512 row blocks, at least 64 rows per block
 static inline int v4_row_blocks(long M, int C) {
     long nb = 1024 / (C / 64);
@@ -615,6 +680,27 @@ int mmseg_instnorm_spade_bwd(const float* dy, const float* x, const float* stat,
                        per_sample, IN_CHUNKS, act_alpha);
     const long n = (long)B * per_sample;
     if (per_sample & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(in_apply_chunks(per_sample), B), dim3(256), 0, st, (const float*)dxn, x, stat, (const float*)ws, dx, per_sample, n, IN_CHUNKS, eps);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+// gamma and beta as the halves of one tensor gb [B * H * W][2C] (see in_apply_gb_kernel); per_sample = H * W * C
+int mmseg_instnorm_spade_fwd_gb(const float* x, const float* gb, float* y, float* stat, float* ws, int B, long per_sample, int C, float eps,
+                                float act_alpha, void* stream) {
+    if ((C & 3) || C <= 0 || per_sample % C != 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(in_partial_kernel, dim3(IN_CHUNKS, B), dim3(256), 0, st, x, ws, per_sample, IN_CHUNKS);
+    hipLaunchKernelGGL(in_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const float*)ws, x, stat, per_sample, IN_CHUNKS, B, eps);
+    hipLaunchKernelGGL(in_apply_gb_kernel, dim3(in_apply_chunks(per_sample), B), dim3(256), 0, st, x, (const float*)stat, gb, y, per_sample, C / 4, act_alpha);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_instnorm_spade_bwd_gb(const float* dy, const float* x, const float* stat, const float* gb, float* dx, float* dgb, float* dxn,
+                                float* ws, int B, long per_sample, int C, float eps, float act_alpha, void* stream) {
+    if ((C & 3) || C <= 0 || per_sample % C != 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(in_bwd_partial_gb_kernel, dim3(IN_CHUNKS, B), dim3(256), 0, st, dy, x, stat, gb, dgb, dxn, ws, per_sample, IN_CHUNKS, C / 4,
+                       act_alpha);
+    const long n = (long)B * per_sample;
     hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(in_apply_chunks(per_sample), B), dim3(256), 0, st, (const float*)dxn, x, stat, (const float*)ws, dx, per_sample, n, IN_CHUNKS, eps);
     return MMSEG_CHECK_LAUNCH();
 }

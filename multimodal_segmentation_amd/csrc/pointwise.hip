@@ -390,6 +390,26 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T
     }
 }
 
+// out[m][0:Ca] = a[m][:], out[m][Ca:Ca+Cb] = b[m][:]  -- two Keras kernels / biases side by side as ONE operand with Ca + Cb output
+// channels (the gamma and beta convolutions of a SPADE unit run as one convolution, layers/spade.py:30-31 of the reference)
+__global__ void concat_cols_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long M, int Ca, int Cb) {
+    const int C = Ca + Cb;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M * C; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / C;
+        const int c = (int)(i - m * C);
+        out[i] = c < Ca ? a[m * Ca + c] : b[m * Cb + (c - Ca)];
+    }
+}
+// da[m][:] += src[m][0:Ca], db[m][:] += src[m][Ca:Ca+Cb]  -- the fused weight / bias gradient back into the two gradient-arena views
+__global__ void split_cols_acc_kernel(const float* __restrict__ src, float* __restrict__ da, float* __restrict__ db, long M, int Ca, int Cb) {
+    const int C = Ca + Cb;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < M * C; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / C;
+        const int c = (int)(i - m * C);
+        if (c < Ca) da[m * Ca + c] += src[i]; else db[m * Cb + (c - Ca)] += src[i];
+    }
+}
+
 extern "C" {
 
 int mmseg_act_fwd(const float* x, float* y, long n, int act, float alpha, void* stream) {
@@ -398,6 +418,16 @@ int mmseg_act_fwd(const float* x, float* y, long n, int act, float alpha, void* 
 }
 int mmseg_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float alpha, void* stream) {
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n / 4, n, act, alpha);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_concat_cols(const float* a, const float* b, float* out, long M, int Ca, int Cb, void* stream) {
+    if (M <= 0 || Ca <= 0 || Cb <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(concat_cols_kernel, dim3(grid_for(M * (Ca + Cb), 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, M, Ca, Cb);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_split_cols_acc(const float* src, float* da, float* db, long M, int Ca, int Cb, void* stream) {
+    if (M <= 0 || Ca <= 0 || Cb <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(split_cols_acc_kernel, dim3(grid_for(M * (Ca + Cb), 256)), dim3(256), 0, (hipStream_t)stream, src, da, db, M, Ca, Cb);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_axpby(const float* a, const float* b, float* out, long n, float sa, float sb, void* stream) {

@@ -45,9 +45,10 @@ def _spade(m, name, anatomy_input, layer, act_alpha):
     """layers/spade.py:26-33 (+ the LeakyReLU that follows it in spade_block when act_alpha >= 0)"""
     a = ops.resize_nearest_down(anatomy_input, layer.shape[1], layer.shape[2])
     a = spade_hidden(m, name, a)
-    gamma = nn.conv(m, name + '_gamma', a)
-    beta = nn.conv(m, name + '_beta', a)
-    return ops.instnorm_spade(layer, gamma, beta, act_alpha)
+    # gamma and beta: two Conv2D(f, 3) of the same 128-channel tensor -> one convolution with 2f output channels (round 3): the
+    # hidden tensor is read once instead of twice, forward and backward; per output channel the same arithmetic
+    gb = nn.conv_pair(m, name + '_gamma', name + '_beta', a)
+    return ops.instnorm_spade_gb(layer, gb, act_alpha)
 
 
 def spade_block(m, n, anatomy_input, layer, fin, fout):

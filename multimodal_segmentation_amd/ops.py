@@ -238,6 +238,25 @@ def _accumulate(dst, src):
     N.call('mmseg_axpby', dst, src, dst, dst.numel(), 1.0, 1.0)
 
 
+def _wgrad_launch(x1, x2, g, dw_flat, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, accumulate):
+    """dW (+)= weight gradient of a convolution; x1 / x2 / g as they are stored (fp32 or the 16-bit storage type)"""
+    need = N.call('mmseg_conv2d_wgrad_workspace', B, Ho, Wo, C1 + C2, Cout, KH, KW)
+    ws = _ws('wgrad', need, g.device)
+    if (_h(x1) or _h(x2) or _h(g)) and N.call('mmseg_conv2d_wgrad_t_supported', Ho, Wo, stride, C1, C2, Cout):
+        # 16-bit operands in HBM: the transposed-staging kernel reads them as they are
+        assert x2 is None or _h(x2) == _h(x1)
+        N.call('mmseg_conv2d_wgrad_t', x1, x2, g, dw_flat, ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
+               stride, ph, pw, ups, accumulate, (1 if _h(x1) else 0) | (4 if _h(g) else 0))
+    elif _h(x1) or _h(x2) or _h(g):
+        # geometry the 16-bit kernel does not take (tiny planes): widen the operands (a copy, no arithmetic)
+        f = lambda t: t if t is None or _h(t) == 0 else t.float()
+        N.call('mmseg_conv2d_wgrad', f(x1), f(x2), f(g), dw_flat, ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
+               stride, ph, pw, ups, accumulate)
+    else:
+        N.call('mmseg_conv2d_wgrad', x1, x2, g, dw_flat, ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
+               stride, ph, pw, ups, accumulate)
+
+
 class _Conv2d(torch.autograd.Function):
     """inputs: activations x1 [, x2], the tape anchor, then non-differentiable arguments.  Weight / bias gradients
     are accumulated into `wgrad` / `bgrad` (views of the owner's gradient arena) instead of being returned."""
@@ -304,22 +323,8 @@ class _Conv2d(torch.autograd.Function):
             ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', M, Cout), dy.device)
             N.call('mmseg_colsum', g if _h(g) == 0 else g.float(), ctx.bgrad, ws, M, Cout, 1.0, 1)
         if ctx.wgrad is not None:
-            need = N.call('mmseg_conv2d_wgrad_workspace', B, Ho, Wo, C1 + C2, Cout, KH, KW)
-            ws = _ws('wgrad', need, dy.device)
             # accumulates straight into the gradient-arena view (the final slab reduction adds to it)
-            if (_h(x1) or _h(x2) or _h(g)) and N.call('mmseg_conv2d_wgrad_t_supported', Ho, Wo, stride, C1, C2, Cout):
-                # 16-bit operands in HBM: the transposed-staging kernel reads them as they are
-                assert x2 is None or _h(x2) == _h(x1)
-                N.call('mmseg_conv2d_wgrad_t', x1, x2, g, ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
-                       stride, ph, pw, ups, 1, (1 if _h(x1) else 0) | (4 if _h(g) else 0))
-            elif _h(x1) or _h(x2) or _h(g):
-                # geometry the 16-bit kernel does not take (tiny planes): widen the operands (a copy, no arithmetic)
-                f = lambda t: t if t is None or _h(t) == 0 else t.float()
-                N.call('mmseg_conv2d_wgrad', f(x1), f(x2), f(g), ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
-                       stride, ph, pw, ups, 1)
-            else:
-                N.call('mmseg_conv2d_wgrad', x1, x2, g, ctx.wgrad.view(-1), ws, ws.numel(), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW,
-                       stride, ph, pw, ups, 1)
+            _wgrad_launch(x1, x2, g, ctx.wgrad.view(-1), B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, ups, 1)
         _grad_done(ctx.wgrad, ctx.bgrad)
         if need_x1 or (x2 is not None and need_x2):
             Cin = C1 + C2
@@ -897,6 +902,126 @@ class _InstNormSpade(torch.autograd.Function):
         N.call('mmseg_instnorm_spade_bwd', _c(dy), x, stat, gamma, beta, dx, dg, db, dxn, ws, B, per, IN_EPS,
                float(ctx.act_alpha))
         return dx, dg, db, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# two convolutions of the same input as ONE (the gamma and beta convolutions of a SPADE unit)
+# ------------------------------------------------------------------------------------------------------
+_pair_cache = {}
+
+
+def _pair_operands(wa, ba, wb, bb, wkey):
+    """[KH, KW, Cin, Ca + Cb] kernel and [Ca + Cb] bias of the fused convolution: the two Keras kernels side by side (a copy per weight
+    version into buffers that live as long as the layer, so that the cached weight images keyed on them stay valid)"""
+    KH, KW, Cin, Ca = wa.shape
+    Cb = wb.shape[3]
+    key = (wkey, wa.data_ptr(), _sid(wa.device))
+    ent = _pair_cache.get(key)
+    if ent is not None and ent[0] == _wver(wkey):
+        return ent[1], ent[2]
+    if ent is None:
+        wcat = torch.empty((KH, KW, Cin, Ca + Cb), dtype=torch.float32, device=wa.device)
+        bcat = torch.empty((Ca + Cb,), dtype=torch.float32, device=wa.device)
+    else:
+        wcat, bcat = ent[1], ent[2]
+    N.call('mmseg_concat_cols', wa, wb, wcat, KH * KW * Cin, Ca, Cb)
+    N.call('mmseg_concat_cols', ba, bb, bcat, 1, Ca, Cb)
+    _pair_cache[key] = (_wver(wkey), wcat, bcat)
+    return wcat, bcat
+
+
+class _Conv2dPair(torch.autograd.Function):
+    """y[..., :Ca] = conv(x, wa) + ba, y[..., Ca:] = conv(x, wb) + bb (3x3 'same', stride 1) as ONE convolution with Ca + Cb output
+    channels: x is read once, the 32-wide tiles of two narrow convolutions become one 64-wide tile, and in the backward pass one
+    weight-gradient and one data-gradient launch replace two of each (plus the addition of the two data gradients).  Per output
+    channel the arithmetic is that of the separate convolutions."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, wa, ba, wb, bb, grads, wkey):
+        x = _c(x)
+        B, H, W, Cin = x.shape
+        KH, KW, Cin2, Ca = wa.shape
+        Cb = wb.shape[3]
+        assert Cin == Cin2 and wb.shape[:3] == wa.shape[:3] and KH % 2 == 1 and KW % 2 == 1
+        Cout = Ca + Cb
+        wcat, bcat = _pair_operands(wa, ba, wb, bb, wkey)
+        pkey = (('pair',) + tuple(wkey[:1]), wkey[1]) if isinstance(wkey, tuple) else None
+        y = _new((B, H, W, Cout), x)
+        wt = _wprep(wcat, KH, KW, Cin, Cout, 0, pkey) if N.call('mmseg_conv2d_fast_path', Cin, 0, Cout, 0) else None
+        _conv_fwd_raw(x, None, wcat, wt, bcat, y, None, B, H, W, Cin, 0, H, W, Cout, KH, KW, 1, KH // 2, KW // 2, 0, 0, 0, 0.0, 0)
+        ctx.geom = (B, H, W, Cin, Ca, Cb, KH, KW)
+        ctx.grads, ctx.pkey, ctx.wcat = grads, pkey, wcat
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, H, W, Cin, Ca, Cb, KH, KW = ctx.geom
+        Cout, M, K = Ca + Cb, B * H * W, KH * KW * Cin
+        dy = _c(dy)
+        wga, bga, wgb, bgb = ctx.grads
+        if bga is not None:
+            tmp = _ws('pair_db', Cout, dy.device)[:Cout]
+            ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', M, Cout), dy.device)
+            N.call('mmseg_colsum', dy if _h(dy) == 0 else dy.float(), tmp, ws, M, Cout, 1.0, 0)
+            N.call('mmseg_split_cols_acc', tmp, bga, bgb, 1, Ca, Cb)
+        if wga is not None:
+            tmp = _ws('pair_dw', K * Cout, dy.device)[:K * Cout]
+            _wgrad_launch(x, None, dy, tmp, B, H, W, Cin, 0, H, W, Cout, KH, KW, 1, KH // 2, KW // 2, 0, 0)
+            N.call('mmseg_split_cols_acc', tmp, wga.view(-1), wgb.view(-1), K, Ca, Cb)
+        _grad_done(wga, bga, wgb, bgb)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _new((B, H, W, Cin), dy, x.dtype)          # a gradient is stored like its tensor
+            if N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0):
+                wf, wt = None, _wprep(ctx.wcat, KH, KW, Cin, Cout, 1, ctx.pkey)
+            else:
+                wf, wt = _ws('wflip', ctx.wcat.numel(), dy.device)[:ctx.wcat.numel()], None
+                N.call('mmseg_conv2d_wflip', ctx.wcat, wf, KH, KW, Cin, Cout)
+            _conv_fwd_raw(dy, None, wf, wt, None, dx, None, B, H, W, Cout, 0, H, W, Cin, KH, KW, 1, KH - 1 - KH // 2, KW - 1 - KW // 2,
+                          0, 0, 0, 0.0, 0)
+        return (dx,) + (None,) * 7
+
+
+def conv2d_pair(x, wa, ba, wb, bb, grads=(None, None, None, None), anchor=None, wkey=None):
+    if all(g is None for g in grads):
+        anchor = None
+    return _Conv2dPair.apply(x, anchor, wa, ba, wb, bb, tuple(grads), wkey)
+
+
+class _InstNormSpadeGB(torch.autograd.Function):
+    """instnorm_spade with gamma and beta as the halves of one tensor gb [B, H, W, 2C] (the output of conv2d_pair)"""
+
+    @staticmethod
+    def forward(ctx, x, gb, act_alpha):
+        x, gb = _c(x), _c(gb)
+        B, C = x.shape[0], x.shape[-1]
+        assert gb.shape == x.shape[:-1] + (2 * C,)
+        per = x.numel() // B
+        y = _new(x.shape, x)
+        stat = _new((B, 2), x)
+        ws = _ws('instnorm', N.call('mmseg_in_workspace_floats', B), x.device)
+        N.call('mmseg_instnorm_spade_fwd_gb', x, gb, y, stat, ws, B, per, C, IN_EPS, float(act_alpha))
+        ctx.act_alpha = act_alpha
+        ctx.save_for_backward(x, stat, gb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stat, gb = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[-1]
+        per = x.numel() // B
+        dx, dgb = _new(x.shape, x), _new(gb.shape, gb)
+        dxn = _ws('instnorm_dxn', x.numel(), x.device)
+        ws = _ws('instnorm', N.call('mmseg_in_workspace_floats', B), x.device)
+        N.call('mmseg_instnorm_spade_bwd_gb', _c(dy), x, stat, gb, dx, dgb, dxn, ws, B, per, C, IN_EPS, float(ctx.act_alpha))
+        return dx, dgb, None
+
+
+def instnorm_spade_gb(x, gb, act_alpha=-1.0):
+    """act( IN(x) * (1 + gb[..., :C]) + gb[..., C:] )"""
+    return _InstNormSpadeGB.apply(x, gb, act_alpha)
 
 
 class _ExpandScalar(torch.autograd.Function):

@@ -417,6 +417,28 @@ def instnorm_spade_bwd(dy, x, stat, gamma, beta, dx, dgamma, dbeta, dxn, ws, B, 
     return 0
 
 
+def concat_cols(a, b, out, M, Ca, Cb):
+    out.reshape(M, Ca + Cb).copy_(torch.cat([a.reshape(M, Ca), b.reshape(M, Cb)], 1)); return 0
+
+
+def split_cols_acc(src, da, db, M, Ca, Cb):
+    s2 = src.reshape(-1)[:M * (Ca + Cb)].reshape(M, Ca + Cb)
+    da.reshape(M, Ca).add_(s2[:, :Ca]); db.reshape(M, Cb).add_(s2[:, Ca:]); return 0
+
+
+def instnorm_spade_fwd_gb(x, gb, y, stat, ws, B, per, C, eps, act_alpha):
+    g2 = gb.reshape(-1, 2 * C)
+    return instnorm_spade_fwd(x, g2[:, :C].contiguous(), g2[:, C:].contiguous(), y, stat, ws, B, per, eps, act_alpha)
+
+
+def instnorm_spade_bwd_gb(dy, x, stat, gb, dx, dgb, dxn, ws, B, per, C, eps, act_alpha):
+    g2 = gb.reshape(-1, 2 * C)
+    dg, db = torch.empty_like(x), torch.empty_like(x)
+    rc = instnorm_spade_bwd(dy, x, stat, g2[:, :C].contiguous(), g2[:, C:].contiguous(), dx, dg, db, dxn, ws, B, per, eps, act_alpha)
+    dgb.reshape(-1, 2 * C).copy_(torch.cat([dg.reshape(-1, C), db.reshape(-1, C)], 1))
+    return rc
+
+
 def dense_workspace_floats(R, K, N):
     return 1
 

@@ -157,6 +157,31 @@ def test_conv2d(case, device):
     check(f_prod, f_ref, inputs, device, param_idx=(1, 2))
 
 
+@pytest.mark.parametrize('B,H,W,Cin,f,alpha', [(2, 12, 10, 128, 32, 0.2), (2, 9, 11, 128, 16, -1.0), (1, 16, 16, 128, 128, 0.2),
+                                               (2, 8, 8, 64, 64, 0.2)])
+def test_spade_gamma_beta_as_one_convolution(B, H, W, Cin, f, alpha, device):
+    """ops.conv2d_pair + ops.instnorm_spade_gb (round 3: the gamma and beta convolutions of a SPADE unit as ONE convolution with 2f output
+    channels, InstanceNorm + modulation reading the halves of its output) against the oracle's two separate convolutions
+    (layers/spade.py:26-33 of the reference): outputs, the gradients of both inputs and of the four parameters"""
+    a = rnd(B, H, W, Cin, seed=1)
+    x = rnd(B, H, W, f, seed=2) * 1.5 + 0.3
+    wg = rnd(3, 3, Cin, f, seed=3, scale=(2.0 / (9 * Cin)) ** 0.5)
+    wb = rnd(3, 3, Cin, f, seed=4, scale=(2.0 / (9 * Cin)) ** 0.5)
+    bg, bb = rnd(f, seed=5, scale=0.1), rnd(f, seed=6, scale=0.1)
+
+    def f_prod(a, x, wg, bg, wb, bb):
+        gb = P.conv2d_pair(a, wg, bg, wb, bb, (wg.gbuf, bg.gbuf, wb.gbuf, bb.gbuf), anchor=_anchor(a), wkey=None)
+        return P.instnorm_spade_gb(x, gb, alpha)
+
+    def f_ref(a, x, wg, bg, wb, bb):
+        gamma, beta = O.conv2d(a, wg, bg), O.conv2d(a, wb, bb)
+        u = O.instance_norm(x) * (1 + gamma) + beta
+        f_ref.pre = u if alpha >= 0 else None
+        return O.leaky_relu(u, alpha) if alpha >= 0 else u
+
+    check(f_prod, f_ref, [a, x, wg, bg, wb, bb], device, param_idx=(2, 3, 4, 5))
+
+
 @pytest.mark.parametrize('shape,relu', [((2, 16, 16, 64), True), ((3, 8, 8, 128), False), ((2, 32, 32, 64), True)])
 def test_batchnorm_train(shape, relu, device):
     C = shape[-1]
