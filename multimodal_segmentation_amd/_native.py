@@ -52,6 +52,8 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-o', LIB_PATH] + srcs
+    if os.environ.get('MMSEG_AB_BUILD') == '1':      # measurement build: the kernel-selection switches of conv.hip read the environment
+        cmd.insert(1, '-DMMSEG_AB')
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -23,6 +23,18 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+// Kernel-selection switches for A/B measurements (tools/*_bench.py).  The product library compiles the defaults
+// in: the environment is only consulted in a build with -DMMSEG_AB (MMSEG_AB_BUILD=1 python -c "... _native.build(force=True)").
+static inline int ab_int(const char* name, int dflt) {
+#ifdef MMSEG_AB
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 struct ConvParams {
     const float* x1;
     const float* x2;
@@ -804,7 +816,7 @@ static int launch_fast_batched(ConvBatch& pb, int n, hipStream_t st) {
 
 // MMSEG_FAST_K64=0 keeps the 16-bit kernels on 32-channel K tiles (A/B measurements)
 static bool fast_k64_enabled() {
-    static const bool on = [] { const char* e = getenv("MMSEG_FAST_K64"); return !(e && e[0] == '0'); }();
+    static const bool on = ab_int("MMSEG_FAST_K64", 1) != 0;
     return on;
 }
 template <int BM, int BN, int WM, int WN>
@@ -838,7 +850,7 @@ static int launch_fwd(const ConvParams& p, bool vec, hipStream_t st) {
     if (vec) g_last_kernel += 500000;                   // the 16-byte-gather instantiation
     dim3 grid(ntm * ntn), block(WM * WN * 64);
     // reduced-precision modes: forward launches with 4-channel gathers multiply 16-bit operands (MMSEG_GENERIC_LP=0: fp32, for A/B runs)
-    static const bool lp_on = [] { const char* e = getenv("MMSEG_GENERIC_LP"); return !(e && e[0] == '0'); }();
+    static const bool lp_on = ab_int("MMSEG_GENERIC_LP", 1) != 0;
     if (vec && !p.transposed && g_conv_bf16 != 0 && lp_on) {
         g_last_kernel += 250000;
         if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true, 1>), grid, block, 0, st, p);
@@ -928,7 +940,7 @@ static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 
 
 // HBM-bound small-channel layers (smallconv.hpp): -1 = not one of them, otherwise the launch's return code
 static int smallconv_dispatch(const ConvParams& p, hipStream_t st) {
-    static const int mask = [] { const char* e = getenv("MMSEG_SMALLCONV"); return e ? atoi(e) : 15; }();     // A/B: 1 reduce fwd, 2 expand fwd
+    static const int mask = ab_int("MMSEG_SMALLCONV", 15);     // A/B: 1 reduce fwd, 2 expand fwd
     const bool on = mask != 0;
     if (!on || p.io != 0 || p.C2 != 0 || p.ups || p.transposed || p.y2 != nullptr || p.w == nullptr || p.osh != 1 || p.osw != 1 || p.ooh != 0 ||
         p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo || !aligned16(p.x1) || !aligned16(p.y) || !aligned16(p.w)) return -1;
@@ -954,7 +966,7 @@ static int smallconv_dispatch(const ConvParams& p, hipStream_t st) {
     // "expand" type: <= 16 gathered values per pixel, L = Cout / 4 lanes per pixel
     const int L = p.Cout / 4;
     if (!(mask & 2)) return -1;
-    static const int only_ks = [] { const char* e = getenv("MMSEG_SMALLCONV_KS"); return e ? atoi(e) : 0; }();
+    static const int only_ks = ab_int("MMSEG_SMALLCONV_KS", 0);
     if (only_ks && p.KH != only_ks) return -1;
     if (p.Cout % 4 != 0 || (L != 2 && L != 4 && L != 16) || p.KH != p.KW || (p.bias && !aligned16(p.bias)) ||
         (p.oscale && !aligned16(p.oscale))) return -1;
@@ -984,7 +996,7 @@ static int smallconv_dispatch(const ConvParams& p, hipStream_t st) {
 
 // the quad-transposed epilogue stores 4 channels per lane: 16-byte (fp32) / 8-byte (16-bit) aligned output rows
 static int quad_epilogue_ok(const ConvParams& p) {
-    static const bool on = [] { const char* e = getenv("MMSEG_QUAD_EPI"); return !(e && e[0] == '0'); }();
+    static const bool on = ab_int("MMSEG_QUAD_EPI", 1) != 0;
     const uintptr_t al = (p.io & 4) ? 7 : 15;
     return (on && (reinterpret_cast<uintptr_t>(p.y) & al) == 0 && (p.y2 == nullptr || (reinterpret_cast<uintptr_t>(p.y2) & al) == 0)) ? 1 : 0;
 }
@@ -1017,7 +1029,7 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (!fast && p.w == nullptr) return (int)hipErrorInvalidValue;   // the generic kernels read the Keras-layout weights: a caller
                                                                      // that only prepared `wt` must not fall through to them
     if (fast) {
-        static const int force_tile = [] { const char* e = getenv("MMSEG_FAST_TILE"); return e ? atoi(e) : 0; }();   // tile A/B measurements
+        static const int force_tile = ab_int("MMSEG_FAST_TILE", 0);   // tile A/B measurements
         if (force_tile == 1) return launch_fast<128, 128, 2, 2>(p, st);
         if (force_tile == 2) return launch_fast<128, 64, 2, 2>(p, st);
         if (force_tile == 3) return launch_fast<64, 64, 2, 2>(p, st);
@@ -2131,7 +2143,7 @@ int mmseg_conv2d_dgrad_parity_all(const float* dy, const float* wt_all, float* d
 // number of pixel splits (slabs) of the weight gradient: enough blocks to fill the chip, at least 512 pixels each
 static int wgrad_target_blocks() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MMSEG_WGRAD_BLOCKS"); v = e ? atoi(e) : 3072; if (v < 1) v = 3072; }
+    if (v < 0) { v = ab_int("MMSEG_WGRAD_BLOCKS", 3072); if (v < 1) v = 3072; }
     return v;
 }
 static int wgrad_splits(long M, long K, int Cout) {
@@ -2150,7 +2162,7 @@ static int wgrad_splits(long M, long K, int Cout) {
 static int wgrad_tr_bnt(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 static int wgrad_tr_enabled() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MMSEG_WGRAD_TR"); v = e ? atoi(e) : 1; }
+    if (v < 0) v = ab_int("MMSEG_WGRAD_TR", 1);
     return v;
 }
 // K tile: 192 rows (3 taps of 64 channels) when that divides K exactly and 128 does not -- the 64-channel 3x3 layers (K = 576),
@@ -2163,7 +2175,7 @@ static int wgrad_tr_splits(long M, long K, int Cout, int* chunk_out) {
     const double cu_rate = 4.0 * 64.0 * 2.4e9;                         // FLOP/s of one CU's fp32 MFMA pipes
     static const double eff[5] = {0.0, 0.55, 0.75, 0.82, 0.85};       // MFMA efficiency by resident blocks per CU (measured shape)
     static int forced = -2;
-    if (forced == -2) { const char* e = getenv("MMSEG_WGRAD_TR_S"); forced = e ? atoi(e) : -1; }
+    if (forced == -2) forced = ab_int("MMSEG_WGRAD_TR_S", -1);
     long maxS = M / 128;
     if (maxS < 1) maxS = 1;
     if (maxS > 4096) maxS = 4096;
@@ -2182,7 +2194,7 @@ static int wgrad_tr_splits(long M, long K, int Cout, int* chunk_out) {
     }
     if (chunk_out) *chunk_out = (int)bestChunk;
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("MMSEG_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = ab_int("MMSEG_WGRAD_DEBUG", 0);
     if (dbg && chunk_out)
         fprintf(stderr, "[wgrad_tr] M=%ld K=%ld N=%d tiles=%ld bpc=%d -> S=%ld chunk=%ld blocks=%ld model=%.1f us\n", M, K, Cout, tiles, bpc,
                 bestS, bestChunk, tiles * bestS, best * 1e6);
@@ -2276,7 +2288,7 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
     }
     {
         // HBM-bound small-channel layers (smallconv.hpp): per-block slabs, then the deterministic slab reduction
-        static const int sc_mask = [] { const char* e = getenv("MMSEG_SMALLCONV"); return e ? atoi(e) : 15; }();   // 4 reduce wgrad, 8 expand wgrad
+        static const int sc_mask = ab_int("MMSEG_SMALLCONV", 15);   // 4 reduce wgrad, 8 expand wgrad
         const bool base = io == 0 && C2 == 0 && !ups && aligned16(x1) && aligned16(dy) && KH == KW;
         const bool one = KH == 1 && stride == 1 && pad_h == 0 && pad_w == 0;
         long cap = wgrad_splits(p.M, p.K, Cout);                 // slabs the caller's workspace holds

@@ -52,6 +52,9 @@ class MMSDNet(BaseNet):
         ops.set_conv_precision(self.conf.get('compute_dtype', 'fp32'))
         # conf.act_storage (build-defined, default 'fp32'): 'half' keeps the trunk's activations / gradients in HBM in the 16-bit type
         ops.set_activation_storage(self.conf.get('act_storage', 'fp32') == 'half')
+        # the library-wide switch above is the process default; every trainer / component of THIS wrapper also carries the pair and
+        # re-enters it on each fit / predict (ops.precision_scope), so a second model of another precision does not disturb this one
+        self._precision = (self.conf.get('compute_dtype', 'fp32'), self.conf.get('act_storage', 'fp32') == 'half')
         # conf.sync_bn (build-defined, default False): BatchNorm batch statistics over all data-parallel ranks (parallel/dp.py)
         from ..parallel import dp
         dp.set_sync_bn(self.conf.get('sync_bn', False))
@@ -64,9 +67,13 @@ class MMSDNet(BaseNet):
                      'D_Image2_trainer'):
             t = getattr(self, name, None)
             if t is not None:
+                t.precision = getattr(self, '_precision', None)
                 t.loss_scale = scale
                 # conf.hip_graphs (build-defined, default False): record each trainer step into a hipGraph and replay it (graphs.py)
                 t.use_graph = bool(self.conf.get('hip_graphs', False))
+        for m in self._generator_models() + [d for d in (getattr(self, 'D_Mask', None), getattr(self, 'D_Image1', None),
+                                                         getattr(self, 'D_Image2', None), getattr(self, 'Balancer', None)) if d is not None]:
+            m.precision = getattr(self, '_precision', None)          # `predict` of a component re-enters this wrapper's precision
 
     def build(self):
         self.apply_compute_dtype()

@@ -42,6 +42,9 @@ class Trainer(object):
         # static loss scale (fp16 compute mode): every seed gradient is multiplied by it, the gradient arenas are divided by it
         # before the optimiser step; 1.0 = off
         self.loss_scale = 1.0
+        # (compute_dtype, 16-bit activation storage) of the model wrapper this trainer belongs to: every fit / predict runs inside
+        # ops.precision_scope(self.precision); None = whatever the library is set to
+        self.precision = None
 
     # keras API used by the executors ---------------------------------------------------------------------------
     @property
@@ -81,13 +84,14 @@ class Trainer(object):
         inputs = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
         targets = list(targets) if isinstance(targets, (list, tuple)) else [targets]
         graph_kw = {k: v for k, v in graph_kw.items() if v is not None}      # (eps=None etc.: the graph functions' defaults)
-        if self.use_graph and not graph_kw and not dp.enabled() and self.device.type == 'cuda':
-            key = graphs.signature(inputs, targets)
-            st = self._graphs.get(key)
-            if st is None:
-                st = self._graphs[key] = graphs.FitGraph(self)
-            return st.run(inputs, targets)
-        return self._fit_eager(inputs, targets, graph_kw)
+        with ops.precision_scope(self.precision):
+            if self.use_graph and not graph_kw and not dp.enabled() and self.device.type == 'cuda':
+                key = graphs.signature(inputs, targets)
+                st = self._graphs.get(key)
+                if st is None:
+                    st = self._graphs[key] = graphs.FitGraph(self)
+                return st.run(inputs, targets)
+            return self._fit_eager(inputs, targets, graph_kw)
 
     @staticmethod
     def _total(terms):
@@ -126,7 +130,7 @@ class Trainer(object):
 
     def predict(self, inputs, **graph_kw):
         ins = [nn.to_device(x, self.device) for x in (inputs if isinstance(inputs, (list, tuple)) else [inputs])]
-        with torch.no_grad():
+        with torch.no_grad(), ops.precision_scope(self.precision):
             outs = self.graph_fn(ins, training=False, **graph_kw)
         return [nn.to_numpy(o) for o in outs]
 

@@ -40,7 +40,6 @@ def set_default_device(dev):
 
 
 _anchors = {}
-_BN_BIAS_GRAD = os.environ.get('MMSEG_BN_BIAS_GRAD', '0') == '1'
 
 
 def anchor(device):
@@ -121,6 +120,7 @@ class Model(object):
         self.arena = self.grad_arena = self.state_arena = None
         self.input_shape = self.output_shape = None
         self.shared = []           # other Models whose weights are part of this one (shared layers)
+        self.precision = None      # (compute_dtype, 16-bit activation storage) of the model wrapper that built it; None: inherit
 
     # ---- construction --------------------------------------------------------------------------------------
     def add_param(self, name, shape, init, trainable=True):
@@ -243,7 +243,7 @@ class Model(object):
         ins = [inputs] if single else list(inputs)
         as_numpy = not isinstance(ins[0], torch.Tensor)
         ts = [to_device(x, self.device) for x in ins]
-        with torch.no_grad():
+        with torch.no_grad(), ops.precision_scope(self.precision):
             out = self.forward(*ts, training=False, **kw)
         if isinstance(out, (list, tuple)):
             return [to_numpy(o) for o in out] if as_numpy else list(out)
@@ -350,8 +350,7 @@ def conv_bn(m, cname, bname, x, training, relu=False, x2=None, upsample=False, y
     conv_dt = half if (half is not None and c1 % 32 == 0 and c2 % 32 == 0 and Cout % 64 == 0) else torch.float32
     bn_dt = half if (half is not None and y16 and Cout % 64 == 0) else torch.float32
     if training or torch.is_grad_enabled():
-        # (MMSEG_BN_BIAS_GRAD=1, experiments only: compute the -- mathematically zero -- bias gradient like the reference does)
-        l = conv(m, cname, x, x2=x2, upsample=upsample, bias_grad=(not training) or _BN_BIAS_GRAD, out_dtype=conv_dt)
+        l = conv(m, cname, x, x2=x2, upsample=upsample, bias_grad=not training, out_dtype=conv_dt)
         return bn(m, bname, l, training, relu=relu, out_dtype=bn_dt)
     return ops.conv2d_bn_infer(x, w.data, b.data if b is not None else None, m.params[bname + '/gamma'].data,
                                m.params[bname + '/beta'].data, m.params[bname + '/moving_mean'].data,

@@ -97,6 +97,34 @@ def set_conv_precision(mode):
     return _PRECISIONS[old]
 
 
+class precision_scope(object):
+    """`with precision_scope((compute_dtype, act16)):` -- run the enclosed launches in the precision of ONE model: the kernel library's
+    mode (and the storage type of the trunk) is set on entry and put back on exit.  Trainers and `predict` enter the scope of the
+    model they belong to, so models of different precisions can live in one process without the caller juggling the library-wide
+    switch (round-2 review); `None` leaves whatever is set."""
+
+    def __init__(self, precision):
+        self.precision = precision
+
+    def __enter__(self):
+        self.prev = None
+        if self.precision is not None:
+            mode, act16 = self.precision
+            cur = (_PRECISIONS[N.call('mmseg_get_conv_precision')], _act16[0] is not None)
+            if cur != (mode, bool(act16)):
+                self.prev = cur
+                set_conv_precision(mode)
+                set_activation_storage(bool(act16))
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            set_activation_storage(False)
+            set_conv_precision(self.prev[0])
+            set_activation_storage(self.prev[1])
+        return False
+
+
 def _conv_geometry(H, W, KH, KW, stride, padding):
     if padding == 'same':
         if stride != 1 or KH % 2 == 0 or KW % 2 == 0:

@@ -320,3 +320,111 @@ def test_config5_mmsdnet_three_modalities_fp16_at_320_bs16_properties():
         assert all(np.isfinite(v) for v in rec) and rec[-1] < rec[0], rec
     finally:
         P.set_conv_precision('fp32')
+
+
+def _blocky_anatomy(rng, Bn, Hn, C=8):
+    """piecewise-constant binary anatomies like the Rounding layer's output: thresholded smooth fields, one-hot over the channels"""
+    from tests import helpers as Hh
+    f = np.stack([Hh.smooth_field(rng, Bn, Hn, Hn, sigma=10.0)[..., 0] for _ in range(C)], -1)
+    s = np.zeros_like(f)
+    np.put_along_axis(s, f.argmax(-1)[..., None], 1.0, axis=-1)
+    s[..., C - 1] = 0.0                     # some pixels without any anatomy channel, as after rounding
+    return s.astype(np.float32)
+
+
+@pytest.mark.parametrize('part', ['decoder', 'segmentor'])
+def test_config3_subgraphs_at_256_against_the_operand_rounding_oracle(part):
+    """BASELINE config #3 (DAFNet-SPADE, bf16 MFMA operands) AT ITS OWN IMAGE SIZE against the oracle, not against the product's own
+    fp32 step: the two sub-graphs downstream of the rounded anatomies -- the SPADE decoder (30 convolutions, now with the fused gamma /
+    beta launches) and the segmentor -- forward and backward on given (s, z) at 256 x 256, batch 2 (what the fp64 oracle affords in
+    a test), with the oracle rounding the operands of exactly the convolutions the product multiplies in bf16.  Outputs within 2x the
+    error of the same oracle run in fp32 (or 1e-2), every weight gradient within 1.5x its per-tensor noise floor (fp32 vs fp64
+    operand-rounding oracle) or 5e-2."""
+    from multimodal_segmentation_amd.configuration import dafnet_spade_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from oracle import models as OM
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    Bn = 2
+    prev = O.set_conv_operand_rounding(torch.bfloat16)
+    try:
+        conf = Hh.make_conf(dafnet_spade_config_chaos, H, batch_size=Bn, compute_dtype='bf16')
+        model = DAFNet(conf)
+        model.build()
+        rng = np.random.RandomState(11)
+        s = _blocky_anatomy(rng, Bn, H)
+        z = rng.standard_normal((Bn, 8)).astype(np.float32)
+        comp, prefix = (model.Decoder, 'DEC/') if part == 'decoder' else (model.Segmentor, 'SEG/')
+        R = rng.standard_normal((Bn, H, H, 1 if part == 'decoder' else 5)).astype(np.float32)
+        res = {}
+        for dt in (torch.float64, torch.float32):
+            Pd = {k: v.clone().requires_grad_(not k.endswith(('moving_mean', 'moving_variance')))
+                  for k, v in Hh.export_dafnet(model, dt).items() if k.startswith(prefix)}
+            st, zt = torch.as_tensor(s, dtype=dt), torch.as_tensor(z, dtype=dt)
+            yo = OM.decoder_spade(st, zt, Pd) if part == 'decoder' else OM.segmentor(st, Pd, True, [])
+            (yo * torch.as_tensor(R, dtype=dt)).sum().backward()
+            res[dt] = (yo.detach().double().numpy(), {k: v.grad.double().numpy() for k, v in Pd.items() if v.grad is not None})
+        comp.zero_grad()
+        with torch.enable_grad():
+            sd, zd = nn.to_device(s, comp.device), nn.to_device(z, comp.device)
+            yp = comp(sd, zd) if part == 'decoder' else comp(sd, training=True)
+            torch.autograd.backward([yp], [nn.to_device(R, comp.device)])
+        yo64, g64 = res[torch.float64]
+        err = np.abs(yp.detach().float().cpu().numpy() - yo64).max()
+        # the yardstick for the output: the SAME oracle run in fp32 -- where a pre-rounding value differs in its last fp32 bits an operand
+        # rounds to the other bf16 neighbour, so two correct implementations decorrelate at the bf16 noise level through 30 convolutions
+        floor_out = np.abs(res[torch.float32][0] - yo64).max()
+        print('%s output: product err %.3e, fp32-oracle err %.3e (both vs the fp64 operand-rounding oracle)' % (part, err, floor_out))
+        assert err <= max(2.0 * floor_out, 1e-2), '%s output: max abs err %.3e (oracle fp32 vs fp64: %.3e)' % (part, err, floor_out)
+        pg = Hh.product_grads(model)
+        worst = []
+        for k, g in g64.items():
+            nrm = np.linalg.norm(g)
+            if nrm < 1e-12 or (k.endswith('/bias') and '_bn' not in k and part == 'segmentor' and not k.endswith('out/bias')):
+                continue            # (segmentor: biases in front of a training-mode BatchNorm have an identically zero gradient)
+            e = np.linalg.norm(pg[k] - g) / nrm
+            floor = np.linalg.norm(res[torch.float32][1][k] - g) / nrm
+            worst.append((e / max(1.5 * floor, 5e-2), e, floor, k))
+        worst.sort(reverse=True)
+        print('%s at 256 x 256 vs the operand-rounding oracle: output err %.3e; worst gradients (ratio, rel-L2, floor):' % (part, err), worst[:4])
+        assert worst and worst[0][0] <= 1.0, worst[:4]
+    finally:
+        O.set_conv_operand_rounding(prev)
+        P.set_conv_precision('fp32')
+
+
+def test_config4_semi_supervised_lmix01_at_256_bs8_properties():
+    """BASELINE config #4 at its own size (DAFNet, l_mix = 0.1 -> 1 labelled + 13 unlabelled volumes, 256 x 256, batch 8; the
+    discriminators with their Spectral regularisers and the STN alignment path are part of every pass): an iteration is a supervised
+    AND an unsupervised pass, each followed by both discriminator phases (dafnet_executor.py:380-387); separate Adam states; the
+    unsupervised trainer has 18 outputs; everything finite; the iteration is bitwise reproducible.  (Parity of both trainers against the
+    oracle: tests/test_dafnet_step.py at 64 x 64.)"""
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
+    from tests import helpers as Hh
+    nn.set_default_device('cuda:0')
+    finals = []
+    for rep in range(2):
+        conf = Hh.make_conf(dafnet_config_chaos, H, batch_size=B, l_mix=0.1)
+        model = DAFNet(conf)
+        model.build()
+        ex = DAFNetExecutor(conf, model)
+        ex.init_train_data(slices_per_volume=8)
+        assert len(model.unsupervised_trainer.specs) == 18 and len(model.supervised_trainer.specs) == 20
+        losses = {n: [] for n in ex.get_loss_names()}
+        ex.train_batch(losses)
+        ex.train_batch(losses)
+        assert model.supervised_trainer.optimizer.iterations == 2 and model.unsupervised_trainer.optimizer.iterations == 2
+        assert model.D_Mask_trainer.optimizer.iterations == 8 and model.D_Image1_trainer.optimizer.iterations == 4
+        assert len(losses['supervised_Mask']) == 4 and len(losses['dis_M']) == 8 and len(losses['dis_X1']) == 4
+        for k in ('supervised_Mask', 'adv_M', 'rec_X', 'adv_X1', 'adv_X2', 'KL', 'rec_Z', 'dis_M', 'dis_X1', 'dis_X2'):
+            assert all(np.isfinite(float(v)) for v in losses[k]), (k, losses[k])
+        theta = model.Anatomy_Fuser.params['theta/kernel'].data
+        assert float(theta.abs().max()) > 0, 'the STN head never received a gradient'
+        for d_ in (model.D_Mask, model.D_Image1, model.D_Image2):
+            assert bool(torch.isfinite(d_.arena).all())
+        finals.append([m.arena.clone() for m in model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]])
+        del model, ex
+    for a, b in zip(*finals):
+        assert torch.equal(a, b), 'two runs of the same two iterations differ'
