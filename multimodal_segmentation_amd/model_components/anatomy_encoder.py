@@ -65,7 +65,23 @@ class AnatomyEncoder(nn.Model):
         logits = nn.conv(self.up, 'conv_anatomy', l)
         soft, rounded = ops.softmax_round(logits)        # Conv2D(.., softmax) + Rounding (anatomy_encoder.py:23-25)
         self.last_soft = soft
-        return rounded if self.conf.rounding else soft
+        out = rounded if self.conf.rounding else soft
+        if _rounding_hook[0] is not None:                # observers of the Rounding boundary (None in production; see set_rounding_hook)
+            out = _rounding_hook[0](self, out)
+        return out
+
+
+_rounding_hook = [None]
+
+
+def set_rounding_hook(fn):
+    """fn(encoder, anatomy) -> anatomy, called with every anatomy factor an encoder returns; None removes it.  The Rounding layer
+    makes everything downstream discontinuous in the encoder's logits, so comparisons against another implementation are made
+    piecewise: a harness installs a hook that swaps in the other side's rounded anatomy with a straight-through gradient
+    (tests/helpers.py::teacher_forcing).  The graphs themselves carry no such argument.  Returns the previous hook."""
+    prev = _rounding_hook[0]
+    _rounding_hook[0] = fn
+    return prev
 
 
 def build(conf, name='Enc_Anatomy', rng=None):

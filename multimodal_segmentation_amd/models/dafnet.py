@@ -109,16 +109,13 @@ class DAFNet(MMSDNet):
         """get_params_expert_pairing (dafnet.py:163-222)"""
         nm = self.conf.num_masks
 
-        def graph(ins, training=True, eps=None, teacher_s=None):
+        def graph(ins, training=True, eps=None):
             x1, x2, z1_input, z2_input = ins
             eps = eps or [None, None]
             with _Frozen([self.D_Mask, self.D_Image1, self.D_Image2]):
                 # encode
                 s1 = self.Encoders_Anatomy[0](x1, training=training)
                 s2 = self.Encoders_Anatomy[1](x2, training=training)
-                if teacher_s is not None:           # parity harness: force the oracle's rounded anatomies
-                    s1 = ops.ste_replace(s1, teacher_s[0])
-                    s2 = ops.ste_replace(s2, teacher_s[1])
                 z1, kl1 = self.Enc_Modality(s1, x1, eps=eps[0])
                 z2, kl2 = self.Enc_Modality(s2, x2, eps=eps[1])
                 # segment (BatchNorm batch statistics per call: these stay separate calls)
@@ -178,7 +175,7 @@ class DAFNet(MMSDNet):
         nm, n = self.conf.num_masks, self.conf.n_pairs
         from ..parallel import dp
 
-        def graph(ins, training=True, eps=None, teacher_s=None):
+        def graph(ins, training=True, eps=None):
             x1_lst, x2_lst = list(ins[:n]), list(ins[n:2 * n])
             rest = list(ins[2 * n:])
             m1_input = rest.pop(0)
@@ -192,9 +189,6 @@ class DAFNet(MMSDNet):
                 # encode every candidate
                 s1_lst = [self.Encoders_Anatomy[0](x, training=training) for x in x1_lst]
                 s2_lst = [self.Encoders_Anatomy[1](x, training=training) for x in x2_lst]
-                if teacher_s is not None:           # parity harness: force the oracle's rounded anatomies
-                    s1_lst = [ops.ste_replace(s, t) for s, t in zip(s1_lst, teacher_s[0])]
-                    s2_lst = [ops.ste_replace(s, t) for s, t in zip(s2_lst, teacher_s[1])]
                 s1, s2 = s1_lst[0], s2_lst[0]
                 z1, kl1 = self.Enc_Modality(s1, x1, eps=eps[0])
                 z2, kl2 = self.Enc_Modality(s2, x2, eps=eps[1])

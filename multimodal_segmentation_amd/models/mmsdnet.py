@@ -177,15 +177,13 @@ class MMSDNet(BaseNet):
     def _graph(self, supervised):
         nm = self.num_masks
 
-        def graph(ins, training=True, eps=None, teacher_s=None):
+        def graph(ins, training=True, eps=None):
             x_list = ins
             M, pairs, n = self.num_mod, self.pairs(), self.n_out()
             assert len(x_list) == M, '%d inputs for %d modalities' % (len(x_list), M)
             eps = eps or [None] * n
             with self._frozen(self.D_Mask):
                 s_list = [self.Encoders_Anatomy[i](x_list[i], training=training) for i in range(M)]
-                if teacher_s is not None:           # parity harness (as in models/dafnet.py): force the oracle's rounded anatomies
-                    s_list = [ops.ste_replace(s, t) for s, t in zip(s_list, teacher_s)]
                 z_list = [self.Enc_Modality(s_list[i], x_list[i], eps=eps[i]) for i in range(M)]
                 m_own = [self.Segmentor(s, training=training) for s in s_list]
                 # deform + fuse every ordered pair (mmsdnet.py:120-121,160-161 for the two pairs of two modalities)

@@ -1349,20 +1349,3 @@ def cat_batch(tensors):
 def split_batch(t, n):
     """inverse of cat_batch for n equal parts"""
     return list(torch.chunk(t, n, dim=0))
-
-
-class _SteReplace(torch.autograd.Function):
-    """Parity harness only: replace a rounded anatomy by a given tensor (teacher forcing across the Rounding
-    discontinuity) while passing the gradient straight through.  No arithmetic."""
-
-    @staticmethod
-    def forward(ctx, s, teacher):
-        return teacher.clone()
-
-    @staticmethod
-    def backward(ctx, g):
-        return g, None
-
-
-def ste_replace(s, teacher):
-    return _SteReplace.apply(s, teacher)

@@ -238,3 +238,44 @@ def sharpen_anatomy_heads(model, factor=40.0, theta_std=0.002, seed=3):
     from multimodal_segmentation_amd import ops
     ops.bump_weight_version()
     return head.name
+
+
+# ---- teacher forcing across the Rounding discontinuity ------------------------------------------------------------
+class _SteReplace(torch.autograd.Function):
+    """replace a rounded anatomy by a given tensor while passing the gradient straight through (no arithmetic)"""
+
+    @staticmethod
+    def forward(ctx, s, teacher):
+        return teacher.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class teacher_forcing(object):
+    """`with teacher_forcing(model, teacher): trainer.fit(...)` -- every anatomy encoder of `model` returns the given anatomies instead
+    of its own rounded output (straight-through gradient) while the block runs.  `teacher`: per modality one tensor, or a list of
+    tensors for the successive calls of that modality's encoder (automated pairing: one per candidate slice); None = no forcing.
+    Installed through model_components.anatomy_encoder.set_rounding_hook: the product graphs carry no test arguments."""
+
+    def __init__(self, model, teacher):
+        self.model, self.teacher = model, teacher
+
+    def __enter__(self):
+        from multimodal_segmentation_amd.model_components import anatomy_encoder as AE
+        self.AE = AE
+        if self.teacher is None:
+            self.prev = AE.set_rounding_hook(AE._rounding_hook[0])
+            return self
+        queues = {id(enc): (list(t) if isinstance(t, (list, tuple)) else [t]) for enc, t in zip(self.model.Encoders_Anatomy, self.teacher)}
+
+        def hook(enc, s):
+            q = queues.get(id(enc))
+            return _SteReplace.apply(s, q.pop(0)) if q else s
+        self.prev = AE.set_rounding_hook(hook)
+        return self
+
+    def __exit__(self, *exc):
+        self.AE.set_rounding_hook(self.prev)
+        return False

@@ -241,7 +241,8 @@ def test_generator_step_with_16bit_trunk_storage_close_to_fp32_storage(dt, decod
             else:
                 for m, w in zip(ms, ref_w):
                     m.set_weights(w)
-            h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']], teacher_s=teacher)
+            with Hh.teacher_forcing(model, teacher):
+                h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']])
             if teacher is None:
                 teacher = [model.last_factors['s1'].detach().clone(), model.last_factors['s2'].detach().clone()]
             res[storage] = {k: h.history[k][0] for k in h.history.keys()}

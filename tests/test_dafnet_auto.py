@@ -71,7 +71,8 @@ def test_automated_pairing_generator_step(supervised, device):
     seg_t = [d['m1'], d['m2'], zeros, zeros] if supervised else [d['m1'], zeros]
     targets = seg_t + [1.0] * 4 + [d['x1'], d['x2'], zeros, zeros] + [1.0] * 4 + [zeros] * 2 + [d['z1'], d['z2']]
     assert len(trainer.output_names) == (20 if supervised else 18)
-    h = trainer.fit(ins, targets, eps=[d['eps1'], d['eps2']], teacher_s=teacher)
+    with Hh.teacher_forcing(model, teacher):
+        h = trainer.fit(ins, targets, eps=[d['eps1'], d['eps2']])
 
     f = model.last_factors
     _cmp(f['w1_def'].detach().cpu().numpy(), oo['w1'].numpy(), 'balancer weights w1')

@@ -144,7 +144,8 @@ def _generator_step_check(decoder, H, supervised, device, compute_dtype='fp32', 
     else:
         seg_t = [d['m1'], d['m1']]
     targets = seg_t + [B1] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [B1] * 4 + [np.zeros(B, np.float32)] * 2 + [d['z1'], d['z2']]
-    h = trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], targets, eps=[d['eps1'], d['eps2']], teacher_s=teacher)
+    with Hh.teacher_forcing(model, teacher):
+        h = trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], targets, eps=[d['eps1'], d['eps2']])
 
     # pre-rounding softmax within tolerance; rounded anatomies: count flips (allowed only where softmax ~ 0.5)
     worst = {}
@@ -293,8 +294,8 @@ def test_generator_step_bf16_compute_close_to_fp32(mode):
             tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [B1] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [B1] * 4 + \
                  [np.zeros(B, np.float32)] * 2 + [d['z1'], d['z2']]
             # teacher-forced at the Rounding layer like every model-level comparison (the fp32 run's anatomies)
-            h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']],
-                                             teacher_s=None if dt == 'fp32' else teacher)
+            with Hh.teacher_forcing(model, None if dt == 'fp32' else teacher):
+                h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']])
             if dt == 'fp32':
                 teacher = [model.last_factors['s1'].detach().clone(), model.last_factors['s2'].detach().clone()]
             res[dt] = {k: h.history[k][0] for k in h.history.keys()}

@@ -227,8 +227,9 @@ def _fixed_batch_property_run(model, conf, d, ref_losses=None):
     gens = model._generator_models()
     tg = [d['m1'], d['m2'], d['m1'], d['m2']] + [1.0] * 4 + [d['x1'], d['x2'], d['x1'], d['x2']] + [1.0] * 4 + [0.0] * 2 + [d['z1'], d['z2']]
     g0 = [m.get_weights() for m in gens]
-    h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']],
-                                     teacher_s=ref_losses['teacher'] if ref_losses else None)
+    from tests import helpers as Hh
+    with Hh.teacher_forcing(model, ref_losses['teacher'] if ref_losses else None):
+        h = model.supervised_trainer.fit([d['x1'], d['x2'], d['z1'], d['z2']], tg, eps=[d['eps1'], d['eps2']])
     vals = {k: h.history[k][0] for k in h.history.keys()}
     assert all(np.isfinite(v) for v in vals.values()), vals
     if ref_losses is not None:

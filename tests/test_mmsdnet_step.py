@@ -68,8 +68,9 @@ def test_mmsdnet_iteration(nmod, device):
     if nmod == 2:       # the reference's target lists (mmsdnet_executor.py:254-258)
         assert [id(a) for a in seg_t] == [id(d[k]) for k in ('m1', 'm2', 'm2', 'm2', 'm1', 'm1')]
         assert [id(a) for a in rec_t] == [id(d[k]) for k in ('x1', 'x2', 'x2', 'x2', 'x1', 'x1')]
-    # teacher-forced at the Rounding boundary through the same `teacher_s` hook of the graph as the DAFNet tests
-    h = model.supervised_trainer.fit([d[k] for k in xk], seg_t + [1.0] * n + rec_t + [0.0] * n, eps=eps, teacher_s=teacher)
+    # teacher-forced at the Rounding boundary through the same encoder hook as the DAFNet tests
+    with Hh.teacher_forcing(model, teacher):
+        h = model.supervised_trainer.fit([d[k] for k in xk], seg_t + [1.0] * n + rec_t + [0.0] * n, eps=eps)
     outs = model.supervised_trainer.last_outputs
     ref = oo['m_list'] + oo['adv_list'] + oo['rec_list'] + oo['kl_list']
     assert len(outs) == len(ref) == 4 * n
