@@ -14,7 +14,7 @@ Extra fields of the JSON line:
                       conv_fast_kernel<128, 128, 2, 2, 0>: algorithmic FLOPs (2*M*K*N per launch, from the launch geometry) / HIP-event
                       time of the sampled launches inside the timed region, against the MFMA peak of the compute dtype;
                       `traffic` = HBM bytes per launch of that kernel from rocprofv3 PMC passes of this same workload
-                      (profiles/r02_conv_traffic.json, keyed by workload and kernel name; null when the workload was not profiled)
+                      (profiles/r03_conv_traffic.json, keyed by workload and kernel name; null when the workload was not profiled)
   roofline_kernels -- the same entry for every convolution kernel instance with >= 0.5 ms of GPU time per step
   roofline_family  -- the two families of round 1 (all forward + data-gradient launches / all weight-gradient launches)
   cpu_baseline     -- the oracle (torch-CPU restatement, "port") timed on this box's host cores on a bounded sample
@@ -295,6 +295,8 @@ def main():
                     help='conf.multi_stream: the mask- and image-discriminator phases of an iteration on concurrent HIP streams (bit-identical '
                          'results, ~2.5 %% faster iteration; off by default because the elapsed time of a kernel that shares the GPU with '
                          "another stream's kernels no longer measures that kernel: the per-kernel roofline entries would read low)")
+    ap.add_argument('--no-multi-stream', action='store_true',
+                    help='the 16-bit modes (--dtype bf16 | f16) run with conf.multi_stream by default (the product default for reduced precision); this keeps them on one stream')
     ap.add_argument('--no-multi-stream-region', action='store_true', help='skip the informational second timed region with conf.multi_stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-conv-timer', action='store_true')
@@ -355,7 +357,10 @@ def main():
             raise SystemExit('--act16 needs --dtype bf16 or f16')
         cfg['act_storage'] = 'half'
         DTYPE_NAME[args.dtype] = DTYPE_NAME[args.dtype].replace('(fp32 accumulate)', '(fp32 accumulate), 16-bit trunk activations in HBM')
-    cfg['multi_stream'] = bool(args.multi_stream)
+    # conf.multi_stream: opt-in for fp32 (the headline keeps per-kernel times meaningful), the product's default in the
+    # reduced-precision modes (their iterations are short enough for the discriminators' small launches to leave the GPU half empty)
+    args.multi_stream = bool(args.multi_stream or (args.dtype != 'f32' and not args.no_multi_stream))
+    cfg['multi_stream'] = args.multi_stream
     if args.multi_stream:
         DTYPE_NAME[args.dtype] += ', discriminator phases on concurrent streams'
     if args.graphs:
@@ -497,9 +502,14 @@ def main():
         wkey = '%s-%s-%d-bs%d-%s-lmix%g' % (args.model if args.model != 'mmsdnet' or args.modalities == 2 else 'mmsdnet3',
                                           args.decoder, H, args.batch, args.dtype + ('-act16' if args.act16 else ''), args.l_mix)
         traffic = {}
-        tpath = os.path.join(ROOT, 'profiles', 'r02_conv_traffic.json')
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('workloads', {}).get(wkey, {})
+        tname = 'r02_conv_traffic.json'
+        for cand in ('r03_conv_traffic.json', 'r02_conv_traffic.json'):      # the latest round's PMC passes that cover this workload
+            tpath = os.path.join(ROOT, 'profiles', cand)
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get('workloads', {}).get(wkey, {})
+                if traffic:
+                    tname = cand
+                    break
         peak = BF16_MFMA_PEAK_TFLOPS if args.dtype in ('bf16', 'f16') else FP32_MFMA_PEAK_TFLOPS
         prec_note = '%s MFMA operands (%s, fp32 accumulation)' % (args.dtype, '16-bit trunk activations + fp32 elsewhere in HBM' if args.act16
                                                                      else 'fp32 tensors in HBM') if args.dtype != 'f32' else 'fp32 MFMA'
@@ -530,7 +540,7 @@ def main():
             # the dominant kernel instance of the step (largest GPU time), named as rocprofv3 names it
             line['roofline'] = dict(per_kernel[0], precision=prec_note,
                                     sampling='every %d-th convolution launch of the timed region bracketed by HIP events' % timer.stride,
-                                    traffic_source=('profiles/r02_conv_traffic.json[%s]' % wkey) if per_kernel[0]['traffic'] else None)
+                                    traffic_source=('profiles/%s[%s]' % (tname, wkey)) if per_kernel[0]['traffic'] else None)
             line['roofline_kernels'] = [e for e in per_kernel if e['gpu_ms_per_step'] >= 0.5 or e['bound'] == 'hbm']
         fam = {}
         for kind, label in (('conv_fwd_kernel', 'forward + data-gradient convolution launches (all template instances)'),

@@ -275,13 +275,13 @@ class DAFNetExecutor(Executor):
             self._train_discriminators(epoch_loss)
 
     def _train_discriminators(self, epoch_loss):
-        """mask-discriminator phase, then image-discriminator phase (dafnet_executor.py:378-386).  conf.multi_stream (build-defined,
-        default False; results are bit-identical either way): the two phases only READ the generator and update different discriminators, so they are queued on two
+        """mask-discriminator phase, then image-discriminator phase (dafnet_executor.py:378-386).  conf.multi_stream (build-defined;
+        default: on in the reduced-precision modes, off in fp32; results are bit-identical either way): the two phases only READ the generator and update different discriminators, so they are queued on two
         HIP streams (the second image discriminator on a third): the discriminators' small launches (a 27 x 27 plane is 92 tiles
         for 256 CUs) then run beside the other phase's full-size inference convolutions instead of alone.  The host issues the
         same launches in the same order (same random streams); scratch buffers and cached weight images are per stream (ops._sid).
         Under data parallelism every rank queues the same collectives in the same order, each behind the launches of its own stream."""
-        if not (bool(self.conf.get('multi_stream', False)) and self.device.type == 'cuda'):
+        if not (bool(self.conf.get('multi_stream', self.conf.get('compute_dtype', 'fp32') != 'fp32')) and self.device.type == 'cuda'):
             self.train_batch_mask_discriminator(epoch_loss)
             self.train_batch_image_discriminator(epoch_loss)
             return

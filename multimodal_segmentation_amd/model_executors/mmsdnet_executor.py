@@ -70,11 +70,11 @@ class MMSDNetExecutor(DAFNetExecutor):
         epoch_loss['val_loss'].append(np.mean([l_mod1, l_mod2, l_mod2_s1def, l_mod2_fused]))
 
     def train_batch(self, epoch_loss):
-        """mmsdnet_executor.py:238-252.  conf.multi_stream (build-defined, default False, bit-identical results): the LAST Z-regressor
+        """mmsdnet_executor.py:238-252.  conf.multi_stream (build-defined, default on in the reduced-precision modes, bit-identical results): the LAST Z-regressor
         step of the iteration (it trains the decoder and the modality encoder) and the mask-discriminator phase (it reads the
         anatomy encoders, the fuser and the segmentor and trains D_Mask) touch disjoint weights, so they are queued on two HIP
         streams -- same launches, same host order, same random streams (see DAFNetExecutor._train_discriminators)."""
-        ms = bool(self.conf.get('multi_stream', False)) and self.device.type == 'cuda'
+        ms = bool(self.conf.get('multi_stream', self.conf.get('compute_dtype', 'fp32') != 'fp32')) and self.device.type == 'cuda'
         if not ms:
             self.train_batch_generators(epoch_loss)
             self.train_batch_mask_discriminator(epoch_loss)

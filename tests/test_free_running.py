@@ -252,7 +252,7 @@ def test_from_init(device):
     """iteration 1 phase by phase from synchronised states (tight, per tensor); iterations 2 and 3 of the same run free-running
     WITHOUT re-synchronisation: the per-tensor weight differences may grow by at most GROWTH per iteration (chaotic dynamics
     through Adam's sign-like first steps and the Rounding layer), and the losses stay together"""
-    B, H = 2, 64
+    B, H = 2, (64 if device == 'cuda' else 48)          # (the CPU stand-in run checks the host logic: a smaller image keeps the suite short)
     conf, model, ex, orc = _build(H, B)
     lines = []
     try:
@@ -280,7 +280,7 @@ def test_along_the_oracle_trajectory(K, device):
     """the one-iteration map of the two implementations at a state that training visits: the oracle trains K iterations alone, then
     iteration K + 1 is run phase by phase from the oracle's transplanted state (warm Adam moments, t > 1 in every trainer, moved
     BatchNorm statistics, a non-identity warp)"""
-    B, H = 2, 64
+    B, H = 2, (64 if device == 'cuda' else 48)
     conf, model, ex, orc = _build(H, B, seed=11)
     for it in range(K):
         orc.train_batch(Hh.to_torch(Hh.make_step_data(B, H, H, seed=500 + it), torch.float32))
