@@ -187,7 +187,7 @@ def _pool_diff(p, o):
     return float((np.abs(p - o) > 1e-3).mean()), float(np.abs(p - o).max())
 
 
-def synced_iteration(model, ex, orc, d, lines, tag):
+def synced_iteration(model, ex, orc, d, lines, tag, gen_bars=None):
     """One iteration of train_batch's schedule, phase by phase, with the oracle's complete state transplanted into the product
     BEFORE every phase: each of the five fits and both pool builds is then the same map applied to the same state on both sides
     (free-running inside the phase, Rounding included), and its result is compared per tensor.  Without the re-synchronisation the
@@ -213,7 +213,7 @@ def synced_iteration(model, ex, orc, d, lines, tag):
     flips = _anatomy_flips(model, orc)
     for k, v in ho.items():
         assert abs(hp.history[k][0] - v) <= 1e-3 * max(1.0, abs(v)) * (10 if flips else 1), (tag, k, hp.history[k][0], v)
-    phase('generator fit', ('sup',), flips)
+    phase('generator fit', ('sup',), flips, gen_bars)
     s_mean = float(model.last_factors['s1'].detach().mean())
     assert 0.01 < s_mean < 0.99, 'the rounded anatomies are trivial (mean %.3f): the free-running comparison would be vacuous' % s_mean
     # mask pools + the two D_Mask fits
@@ -290,6 +290,9 @@ def test_along_the_oracle_trajectory(K, device):
     assert float(model.Anatomy_Fuser.params['theta/kernel'].data.abs().max()) > 0
     lines = []
     try:
-        synced_iteration(model, ex, orc, Hh.make_step_data(B, H, H, seed=900), lines, 'iteration %d of the oracle trajectory' % (K + 1))
+        # with warm Adam moments (10 % of m is this step's gradient) the generator fit agrees far more tightly than at t = 1: measured
+        # 3.4e-4 (m) / 3.5e-5 (v) on the MI355X and on the stand-in alike (profiles/r03_free_running_parity_trajectory_K8_*.txt)
+        synced_iteration(model, ex, orc, Hh.make_step_data(B, H, H, seed=900), lines, 'iteration %d of the oracle trajectory' % (K + 1),
+                         gen_bars=(2e-3, 4e-4, BAR_W, BAR_FLIP_FRAC))
     finally:
         _write_report('trajectory_K%d' % K, device, lines)
