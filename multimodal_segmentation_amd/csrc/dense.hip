@@ -158,6 +158,33 @@ __global__ void dense_dgrad_kernel(const float* __restrict__ dy, const float* __
     }
 }
 
+// dx[b][k] = sum_n dy[b][n] * W[k][n] for a dense layer with FEW inputs and many outputs (the SPADE decoder's Dense(8 -> H*W/8),
+// decoder.py:68 of the reference): one block per row b, the threads stride over n (coalesced reads of dy[b][:] and of every row of
+// W), K <= 16 accumulators per thread, fixed-order block sums.  The 64-rows-of-W-per-block kernel above is ONE block for K = 8 and
+// walks N = 8192 in 64 synchronised chunks (87 us); this one is latency of a single pass.
+template <int KMAX>
+__global__ __launch_bounds__(256) void dense_dgrad_smallk_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int K, int N) {
+    __shared__ float red[17];
+    const int b = blockIdx.x;
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float d = dy[(size_t)b * N + n];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) acc[k] = fmaf(d, w[(size_t)k * N + n], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            const float t = block_sum(acc[k], red);
+            if (threadIdx.x == 0) dx[(size_t)b * K + k] = t;
+        }
+    }
+}
+
 // dW[k][n] = sum_b x[b][k] * dy[b][n]
 __global__ void dense_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
                                    int R, int K, int N, int accumulate) {
@@ -206,6 +233,10 @@ int mmseg_dense_fwd(const float* x, const float* w, const float* bias, float* y,
 }
 int mmseg_dense_dgrad(const float* dy, const float* w, float* dx, int R, int K, int N, void* stream) {
     if (R < 1 || R > 32) return (int)hipErrorInvalidValue;
+    if (K <= 16 && N >= 1024) {
+        hipLaunchKernelGGL(dense_dgrad_smallk_kernel<16>, dim3(R), dim3(256), 0, (hipStream_t)stream, dy, w, dx, K, N);
+        return MMSEG_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(dense_dgrad_kernel, dim3((K + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, w, dx, R, K, N);
     return MMSEG_CHECK_LAUNCH();
 }

@@ -207,9 +207,9 @@ def interpolate_spline(train_points, train_values, query_points):
     A = _phi(_pairwise_sq_dist(c))
     Bm = torch.cat([c, torch.ones_like(c[..., :1])], 2)
     left = torch.cat([A, Bm.transpose(1, 2)], 1)
-    right = torch.cat([Bm, torch.zeros(b, d + 1, d + 1, dtype=c.dtype)], 1)
+    right = torch.cat([Bm, torch.zeros(b, d + 1, d + 1, dtype=c.dtype, device=c.device)], 1)
     lhs = torch.cat([left, right], 2)
-    rhs = torch.cat([f, torch.zeros(b, d + 1, k, dtype=c.dtype)], 1)
+    rhs = torch.cat([f, torch.zeros(b, d + 1, k, dtype=c.dtype, device=c.device)], 1)
     wv = torch.linalg.solve(lhs, rhs)
     w, v = wv[:, :n], wv[:, n:]
     rbf = _phi(_cross_sq_dist(query_points, c)) @ w
@@ -243,14 +243,14 @@ def resampler(data, warp):
 def tps_warp(vol, theta, cp_dims=(5, 5)):
     """ThinPlateSpline2D.call, inverse=False, order=2 (layers/stn_spline.py:36-67)."""
     B, H, W, C = vol.shape
-    cp = nd_grid(cp_dims, vol.dtype)          # [1, 25, 2]
-    q = nd_grid((H, W), vol.dtype)            # [1, HW, 2]
+    cp = nd_grid(cp_dims, vol.dtype).to(vol.device)          # [1, 25, 2]
+    q = nd_grid((H, W), vol.dtype).to(vol.device)            # [1, HW, 2]
     locs = []
     for i in range(B):                        # tf.map_fn over the batch (stn_spline.py:58)
         locs.append(interpolate_spline(cp, cp + theta[i][None], q)[0])
     loc = torch.stack(locs, 0)
     loc = torch.flip(loc, dims=[-1])          # (row, col) -> (x, y)   (stn_spline.py:60)
-    loc = loc * torch.tensor([W - 1, H - 1], dtype=vol.dtype)  # stn_spline.py:62-63
+    loc = loc * torch.tensor([W - 1, H - 1], dtype=vol.dtype, device=vol.device)  # stn_spline.py:62-63
     return resampler(vol, loc).reshape(B, H, W, C)
 
 

@@ -239,7 +239,8 @@ def test_softmax_round(C, device):
 
 @pytest.mark.parametrize('R,K,N,act', [(8, 28800, 32, 'leaky'), (8, 32, 8, None), (8, 1000, 100, 'tanh'),
                                        (8, 8, 2048, None), (8, 5000, 1, None), (16, 300, 50, None),
-                                       (16, 46656, 1, None), (32, 46656, 1, None), (12, 4098, 1, None), (16, 5000, 3, 'leaky')])
+                                       (16, 46656, 1, None), (32, 46656, 1, None), (12, 4098, 1, None), (16, 5000, 3, 'leaky'),
+                                       (32, 8, 8192, None), (5, 16, 1500, 'tanh')])       # few inputs, many outputs: the small-K data gradient
 def test_dense(R, K, N, act, device):
     x, w, b = rnd(R, K, seed=12), rnd(K, N, seed=13, scale=K ** -0.5), rnd(N, seed=14, scale=0.1)
 

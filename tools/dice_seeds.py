@@ -5,10 +5,12 @@ forcing) from identically seeded weights on identical batches and draws, evaluat
 stochastic-weight-averaged model (callbacks/swa.py: running mean of the weights, BatchNorm moving statistics included) -- on a
 fixed synthetic validation split of 256 paired slices.
 
-    python tools/dice_seeds.py <seed> <product|oracle|standin> [iterations=500] [size=64] [batch=4] [lr=1e-3] [swa_from=350] [swa_every=10]
+    python tools/dice_seeds.py <seed> <product|oracle|standin|oracle_gpu> [iterations=500] [size=64] [batch=4] [lr=1e-3] [swa_from=350] [swa_every=10]
         product: the HIP kernels on the GPU; oracle: oracle/ on the CPU; standin: the PRODUCT's host logic (graphs, trainers, pools,
         caches) on tests/cpu_backend.py, i.e. torch-CPU arithmetic under the product's Python -- separates "host logic" from "kernel
-        numerics" without a GPU.  DICE_LABEL=<name> relabels the RESULT line (e.g. a second oracle realisation with ORACLE_THREADS=1)
+        numerics" without a GPU.  oracle_gpu: the ORACLE's own code (oracle/*.py, plain torch ops) with its tensors on the GPU, i.e. on
+        torch-ROCm's library kernels (MIOpen / rocBLAS) -- a third implementation of the same arithmetic that owes nothing to csrc/, and
+        fast enough for many seeds.  DICE_LABEL=<name> relabels the RESULT line (e.g. a second oracle realisation with ORACLE_THREADS=1)
     python tools/dice_seeds.py summary <log> [<log> ...]        # mean +- 95 % CI of (product - oracle) over the seeds
     DICE_CHECKS=10,25,50,100,200 python tools/dice_seeds.py ...  # also evaluate the LIVE model after these iterations (CHECK lines)
 
@@ -121,6 +123,9 @@ def main():
     odt = torch.float32                                   # the oracle runs in fp32 here (CPU time); the product is fp32 too
     torch.set_num_threads(int(os.environ.get('ORACLE_THREADS', max(1, min(len(os.sched_getaffinity(0)), 16)))))
     label = os.environ.get('DICE_LABEL', side)
+    odev = torch.device('cuda:0' if side == 'oracle_gpu' else 'cpu')        # where the oracle's tensors live
+    if side == 'oracle_gpu':
+        side = 'oracle'
     if side in ('oracle', 'standin'):                     # no GPU: build the identically seeded model on the CPU stand-in (oracle: to export weights)
         from tests import cpu_backend as _cb
         _cb.install(); nn.set_default_device('cpu')
@@ -129,7 +134,8 @@ def main():
     conf = Hh.make_conf(dafnet_config_chaos, H, batch_size=B, lr=lr, seed=10 + seed)
     conf.d_mask_params['lr'] = lr; conf.d_image_params['lr'] = lr
     model = DAFNet(conf); model.build()
-    orc = OD.DAFNetOracle(Hh.export_dafnet(model, odt), dict(decoder_type='film', lr=lr, d_lr=lr)) if side == 'oracle' else None
+    orc = OD.DAFNetOracle({k: v.to(odev) for k, v in Hh.export_dafnet(model, odt).items()},
+                          dict(decoder_type='film', lr=lr, d_lr=lr)) if side == 'oracle' else None
     ex = DAFNetExecutor.__new__(DAFNetExecutor); ex.conf, ex.model = conf, model; ex.device = model.D_Mask.device
     train = synthetic.SyntheticPairedData(conf.input_shape, 4, list(range(6)), 8, 77)             # fixed split for every seed
     val = synthetic.SyntheticPairedData(conf.input_shape, 4, list(range(14, 30)), 16, 78)          # 16 volumes x 16 = 256 slices
@@ -189,7 +195,7 @@ def main():
         for i, (x, m) in enumerate(((x1, m1), (x2, m2))):
             if side == 'oracle':
                 with torch.no_grad():
-                    preds = [OM.segmentor(orc.enc(torch.as_tensor(x[j:j + 32], dtype=odt), i), orc.P, False, None).numpy()
+                    preds = [OM.segmentor(orc.enc(torch.as_tensor(x[j:j + 32], dtype=odt).to(odev), i), orc.P, False, None).cpu().numpy()
                              for j in range(0, len(x), 32)]
             else:
                 preds = [model.Segmentor.predict(model.Encoders_Anatomy[i].predict(x[j:j + 32])) for j in range(0, len(x), 32)]
@@ -205,7 +211,7 @@ def main():
             o2 = OD.DAFNetOracle(P, dict(orc.conf))
             with torch.no_grad():
                 for i, (x, m) in enumerate(((x1, m1), (x2, m2))):
-                    preds = [OM.segmentor(o2.enc(torch.as_tensor(x[j:j + 32], dtype=odt), i), P, False, None).numpy() for j in range(0, len(x), 32)]
+                    preds = [OM.segmentor(o2.enc(torch.as_tensor(x[j:j + 32], dtype=odt).to(odev), i), P, False, None).cpu().numpy() for j in range(0, len(x), 32)]
                     out.append(costs.dice(m, np.concatenate(preds, 0), binarise=True))
         else:
             live = [m.get_weights() for m in seg_models()]
@@ -224,7 +230,7 @@ def main():
         if side in ('product', 'standin'):
             loss = product_step(d)
         else:
-            loss = orc.train_batch(Hh.to_torch(d, odt), supervised=True)['supervised_Mask']
+            loss = orc.train_batch({k: v.to(odev) for k, v in Hh.to_torch(d, odt).items()}, supervised=True)['supervised_Mask']
         if it >= swa_from and (it - swa_from) % swa_every == 0:
             swa_update()
         if it % 50 == 0 or it == iters - 1:
@@ -239,7 +245,7 @@ def main():
             # that bias, which the BatchNorm -- and its moving mean -- absorbs without any effect on the output)
             keep = lambda k: k.startswith(('EA0/', 'EA1/', 'EAS/', 'SEG/')) and k.endswith(('/kernel', '/gamma', '/beta', '/moving_variance'))
             if side == 'oracle':
-                ws = [v.detach().double().numpy().ravel() for k, v in sorted(orc.P.items()) if keep(k)]
+                ws = [v.detach().double().cpu().numpy().ravel() for k, v in sorted(orc.P.items()) if keep(k)]
             else:           # the same tensors under the oracle's names (the encoders' shared up-path counted once)
                 ws = [v.detach().double().cpu().numpy().ravel() for k, v in sorted(Hh.export_dafnet(model, torch.float32).items()) if keep(k)]
             w = np.concatenate(ws)
