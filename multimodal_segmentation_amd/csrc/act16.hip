@@ -8,32 +8,6 @@
 // model_components/segmentor.py:16-21.
 #include "common.hpp"
 
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-
-// four consecutive elements number 4*i4 .. 4*i4+3 of a tensor stored with element code H
-template <int H> __device__ __forceinline__ f32x4 ld4(const void* p, long i4) {
-    if constexpr (H == 0) return reinterpret_cast<const f32x4*>(p)[i4];
-    else if constexpr (H == 1) {
-        const bf16x4_t v = reinterpret_cast<const bf16x4_t*>(p)[i4];
-        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-    } else {
-        const f16x4_t v = reinterpret_cast<const f16x4_t*>(p)[i4];
-        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-    }
-}
-template <int H> __device__ __forceinline__ void st4(void* p, long i4, f32x4 v) {
-    if constexpr (H == 0) reinterpret_cast<f32x4*>(p)[i4] = v;
-    else if constexpr (H == 1) reinterpret_cast<bf16x4_t*>(p)[i4] = bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-    else reinterpret_cast<f16x4_t*>(p)[i4] = f16x4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-}
-template <int H> __device__ __forceinline__ float ld1(const void* p, long i) {
-    if constexpr (H == 0) return reinterpret_cast<const float*>(p)[i];
-    else if constexpr (H == 1) return (float)reinterpret_cast<const __bf16*>(p)[i];
-    else return (float)reinterpret_cast<const _Float16*>(p)[i];
-}
-
 // ---- BatchNorm ------------------------------------------------------------------------------------------------------------------
 // C % 64 == 0 (every BatchNorm of the trunk).  grid (row blocks, C/64), block = 16 float4 column lanes x 16 row lanes.
 // MODE 0: (x - shift, (x - shift)^2), shift = x[0][c]; MODE 1: (g, g * xhat), g = dy * [y > 0 if relu]
@@ -280,6 +254,27 @@ __global__ __launch_bounds__(256) void act16_bwd_kernel(const void* __restrict__
         }
     }
 }
+// part[blockIdx.x][c] = sum over this block's rows of x[., c] for a tensor stored with element code H (C % 64 == 0; grid (row blocks,
+// C / 64), block = 16 float4 column lanes x 16 row lanes): the bias gradient of a convolution whose output gradient is a 16-bit tensor
+template <int H>
+__global__ __launch_bounds__(256) void colsum16_partial_kernel(const void* __restrict__ x, float* __restrict__ part, long M, int C,
+                                                               long rows_per_block) {
+    __shared__ f32x4 sm[16][16];
+    const int tid = threadIdx.x, c4 = tid & 15, rl = tid >> 4;
+    const int C4 = C >> 2, col = blockIdx.y * 16 + c4;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (long r = r0 + rl; r < r1; r += 16) s += ld4<H>(x, r * C4 + col);
+    sm[rl][c4] = s;
+    __syncthreads();
+    if (tid < 16) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][tid];
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + (size_t)(blockIdx.y * 16 + tid) * 4) = t;
+    }
+}
 // out[c] (+)= sum over the row blocks of part[b][c]; one block per channel, fixed order
 __global__ __launch_bounds__(256) void colsum16_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C,
                                                              int accumulate) {
@@ -450,6 +445,23 @@ int mmseg_act_bwd_bias_t(const void* dy, const void* y, void* dx, float* bias_gr
     return MMSEG_CHECK_LAUNCH();
 }
 
+
+// out[c] (+)= sum over the M rows of x[., c], x stored with element code h (C % 64 == 0; ws = mmseg_colsum_workspace_floats(M, C))
+int mmseg_colsum_t(const void* x, float* out, float* ws, long M, int C, int accumulate, int h, void* stream) {
+    if (!hcode_ok(h) || M <= 0 || C <= 0 || (C % 64) != 0 || ws == nullptr) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    long nb = 1024 / (C / 64);
+    if (nb > 512) nb = 512;
+    const long maxb = (M + 63) / 64;
+    if (nb > maxb) nb = maxb;
+    if (nb < 1) nb = 1;
+    const long rpb = (M + nb - 1) / nb;
+#define L(HH) hipLaunchKernelGGL((colsum16_partial_kernel<HH>), dim3((unsigned)nb, C / 64), dim3(256), 0, st, x, ws, M, C, rpb)
+    DISPATCH_H(h, L);
+#undef L
+    hipLaunchKernelGGL(colsum16_final_kernel, dim3(C), dim3(256), 0, st, (const float*)ws, out, (int)nb, C, accumulate);
+    return MMSEG_CHECK_LAUNCH();
+}
 
 // out[B*H*W][96] (element code hy: 1 bf16 / 2 fp16) = im2col of x[B,H,W,8] (element code hx) for a 3x3 stride-1 'same' convolution,
 // K index = tap * 8 + channel, columns 72..95 zero -- see im2col8_kernel

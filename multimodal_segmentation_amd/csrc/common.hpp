@@ -61,3 +61,31 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (orig >> 3);
 }
+
+// ---- tensors stored as fp32 or as a 16-bit type (element code H: 0 = fp32, 1 = bf16, 2 = fp16; reduced-precision storage) -------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+// four consecutive elements number 4*i4 .. 4*i4+3 of a tensor stored with element code H
+template <int H> __device__ __forceinline__ f32x4 ld4(const void* p, long i4) {
+    if constexpr (H == 0) return reinterpret_cast<const f32x4*>(p)[i4];
+    else if constexpr (H == 1) {
+        const bf16x4_t v = reinterpret_cast<const bf16x4_t*>(p)[i4];
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else {
+        const f16x4_t v = reinterpret_cast<const f16x4_t*>(p)[i4];
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+template <int H> __device__ __forceinline__ void st4(void* p, long i4, f32x4 v) {
+    if constexpr (H == 0) reinterpret_cast<f32x4*>(p)[i4] = v;
+    else if constexpr (H == 1) reinterpret_cast<bf16x4_t*>(p)[i4] = bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    else reinterpret_cast<f16x4_t*>(p)[i4] = f16x4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+}
+template <int H> __device__ __forceinline__ float ld1(const void* p, long i) {
+    if constexpr (H == 0) return reinterpret_cast<const float*>(p)[i];
+    else if constexpr (H == 1) return (float)reinterpret_cast<const __bf16*>(p)[i];
+    else return (float)reinterpret_cast<const _Float16*>(p)[i];
+}
+

@@ -47,7 +47,10 @@ def _spade(m, name, anatomy_input, layer, act_alpha):
     a = spade_hidden(m, name, a)
     # gamma and beta: two Conv2D(f, 3) of the same 128-channel tensor -> one convolution with 2f output channels (round 3): the
     # hidden tensor is read once instead of twice, forward and backward; per output channel the same arithmetic
-    gb = nn.conv_pair(m, name + '_gamma', name + '_beta', a)
+    # (with conf.act_storage = 'half' the fused tensor and its gradient live in HBM in the 16-bit type, like the hidden tensor)
+    import torch
+    half = ops.act16_dtype()
+    gb = nn.conv_pair(m, name + '_gamma', name + '_beta', a, out_dtype=half if half is not None else torch.float32)
     return ops.instnorm_spade_gb(layer, gb, act_alpha)
 
 

@@ -314,13 +314,14 @@ def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, ups
                       wkey=(id(w), id(w.owner)), out_dtype=out_dtype)
 
 
-def conv_pair(m, name_a, name_b, x):
+def conv_pair(m, name_a, name_b, x, out_dtype=torch.float32):
     """two 3x3 'same' convolutions of the same input as one launch with their output channels side by side (ops.conv2d_pair): the
     gamma and beta convolutions of a SPADE unit (reference layers/spade.py:30-31)"""
     wa, ba = m.params[name_a + '/kernel'], m.params[name_a + '/bias']
     wb, bb = m.params[name_b + '/kernel'], m.params[name_b + '/bias']
     grads = (wa.g(), ba.g(), wb.g(), bb.g())
-    return ops.conv2d_pair(x, wa.data, ba.data, wb.data, bb.data, grads, anchor=anchor(x.device), wkey=(id(wa), id(wa.owner)))
+    return ops.conv2d_pair(x, wa.data, ba.data, wb.data, bb.data, grads, anchor=anchor(x.device), wkey=(id(wa), id(wa.owner)),
+                           out_dtype=out_dtype)
 
 
 def dense(m, name, x, act=None, alpha=0.0):

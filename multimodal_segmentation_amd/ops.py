@@ -965,7 +965,7 @@ class _Conv2dPair(torch.autograd.Function):
     channel the arithmetic is that of the separate convolutions."""
 
     @staticmethod
-    def forward(ctx, x, anchor, wa, ba, wb, bb, grads, wkey):
+    def forward(ctx, x, anchor, wa, ba, wb, bb, grads, wkey, out_dtype=torch.float32):
         x = _c(x)
         B, H, W, Cin = x.shape
         KH, KW, Cin2, Ca = wa.shape
@@ -974,8 +974,8 @@ class _Conv2dPair(torch.autograd.Function):
         Cout = Ca + Cb
         wcat, bcat = _pair_operands(wa, ba, wb, bb, wkey)
         pkey = (('pair',) + tuple(wkey[:1]), wkey[1]) if isinstance(wkey, tuple) else None
-        y = _new((B, H, W, Cout), x)
         wt = _wprep(wcat, KH, KW, Cin, Cout, 0, pkey) if N.call('mmseg_conv2d_fast_path', Cin, 0, Cout, 0) else None
+        y = _new((B, H, W, Cout), x, out_dtype if wt is not None else torch.float32)     # (16-bit outputs: fast path only)
         _conv_fwd_raw(x, None, wcat, wt, bcat, y, None, B, H, W, Cin, 0, H, W, Cout, KH, KW, 1, KH // 2, KW // 2, 0, 0, 0, 0.0, 0)
         ctx.geom = (B, H, W, Cin, Ca, Cb, KH, KW)
         ctx.grads, ctx.pkey, ctx.wcat = grads, pkey, wcat
@@ -992,7 +992,10 @@ class _Conv2dPair(torch.autograd.Function):
         if bga is not None:
             tmp = _ws('pair_db', Cout, dy.device)[:Cout]
             ws = _ws('colsum', N.call('mmseg_colsum_workspace_floats', M, Cout), dy.device)
-            N.call('mmseg_colsum', dy if _h(dy) == 0 else dy.float(), tmp, ws, M, Cout, 1.0, 0)
+            if _h(dy) and Cout % 64 == 0:
+                N.call('mmseg_colsum_t', dy, tmp, ws, M, Cout, 0, _h(dy))
+            else:
+                N.call('mmseg_colsum', dy if _h(dy) == 0 else dy.float(), tmp, ws, M, Cout, 1.0, 0)
             N.call('mmseg_split_cols_acc', tmp, bga, bgb, 1, Ca, Cb)
         if wga is not None:
             tmp = _ws('pair_dw', K * Cout, dy.device)[:K * Cout]
@@ -1009,13 +1012,13 @@ class _Conv2dPair(torch.autograd.Function):
                 N.call('mmseg_conv2d_wflip', ctx.wcat, wf, KH, KW, Cin, Cout)
             _conv_fwd_raw(dy, None, wf, wt, None, dx, None, B, H, W, Cout, 0, H, W, Cin, KH, KW, 1, KH - 1 - KH // 2, KW - 1 - KW // 2,
                           0, 0, 0, 0.0, 0)
-        return (dx,) + (None,) * 7
+        return (dx,) + (None,) * 8
 
 
-def conv2d_pair(x, wa, ba, wb, bb, grads=(None, None, None, None), anchor=None, wkey=None):
+def conv2d_pair(x, wa, ba, wb, bb, grads=(None, None, None, None), anchor=None, wkey=None, out_dtype=torch.float32):
     if all(g is None for g in grads):
         anchor = None
-    return _Conv2dPair.apply(x, anchor, wa, ba, wb, bb, tuple(grads), wkey)
+    return _Conv2dPair.apply(x, anchor, wa, ba, wb, bb, tuple(grads), wkey, out_dtype)
 
 
 class _InstNormSpadeGB(torch.autograd.Function):
@@ -1030,7 +1033,7 @@ class _InstNormSpadeGB(torch.autograd.Function):
         y = _new(x.shape, x)
         stat = _new((B, 2), x)
         ws = _ws('instnorm', N.call('mmseg_in_workspace_floats', B), x.device)
-        N.call('mmseg_instnorm_spade_fwd_gb', x, gb, y, stat, ws, B, per, C, IN_EPS, float(act_alpha))
+        N.call('mmseg_instnorm_spade_fwd_gb_t', x, gb, y, stat, ws, B, per, C, IN_EPS, float(act_alpha), _h(gb))
         ctx.act_alpha = act_alpha
         ctx.save_for_backward(x, stat, gb)
         return y
@@ -1040,10 +1043,10 @@ class _InstNormSpadeGB(torch.autograd.Function):
         x, stat, gb = ctx.saved_tensors
         B, C = x.shape[0], x.shape[-1]
         per = x.numel() // B
-        dx, dgb = _new(x.shape, x), _new(gb.shape, gb)
+        dx, dgb = _new(x.shape, x), _new(gb.shape, gb, gb.dtype)          # a gradient is stored like its tensor
         dxn = _ws('instnorm_dxn', x.numel(), x.device)
         ws = _ws('instnorm', N.call('mmseg_in_workspace_floats', B), x.device)
-        N.call('mmseg_instnorm_spade_bwd_gb', _c(dy), x, stat, gb, dx, dgb, dxn, ws, B, per, C, IN_EPS, float(ctx.act_alpha))
+        N.call('mmseg_instnorm_spade_bwd_gb_t', _c(dy), x, stat, gb, dx, dgb, dxn, ws, B, per, C, IN_EPS, float(ctx.act_alpha), _h(gb))
         return dx, dgb, None
 
 

@@ -439,6 +439,22 @@ def instnorm_spade_bwd_gb(dy, x, stat, gb, dx, dgb, dxn, ws, B, per, C, eps, act
     return rc
 
 
+def instnorm_spade_fwd_gb_t(x, gb, y, stat, ws, B, per, C, eps, act_alpha, h):
+    return instnorm_spade_fwd_gb(x, gb.float(), y, stat, ws, B, per, C, eps, act_alpha)
+
+
+def instnorm_spade_bwd_gb_t(dy, x, stat, gb, dx, dgb, dxn, ws, B, per, C, eps, act_alpha, h):
+    tmp = torch.empty(dgb.shape, dtype=torch.float32)
+    rc = instnorm_spade_bwd_gb(dy, x, stat, gb.float(), dx, tmp, dxn, ws, B, per, C, eps, act_alpha)
+    dgb.copy_(tmp.to(dgb.dtype))
+    return rc
+
+
+def colsum_t(x, out, ws, M, C, accumulate, h):
+    s = x.float().reshape(M, C).sum(0)
+    out.copy_(out + s if accumulate else s); return 0
+
+
 def dense_workspace_floats(R, K, N):
     return 1
 

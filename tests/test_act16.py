@@ -213,6 +213,41 @@ def test_activated_conv_with_16bit_output_has_a_correct_backward(mode):
         assert err <= tol, '%s: rel L2 %.3e' % (name, err)
 
 
+def test_spade_gamma_beta_tensor_in_16_bits(mode):
+    """the fused gamma / beta tensor of a SPADE unit and its gradient stored in 16 bits (conf.act_storage = 'half'): the fused convolution
+    writes exactly the rounding of its fp32-storage output; InstanceNorm + modulation read a 16-bit gb and write a 16-bit dgb that is
+    bit for bit the rounding of the fp32 one (same arithmetic, only the loads and stores differ); the typed column sums equal the
+    fp32 ones on the widened tensor"""
+    B, H, Cin, f = 2, 24, 128, 32
+    a = rnd(B, H, H, Cin, seed=41).to(mode).to(DEV)
+    wg = (rnd(3, 3, Cin, f, seed=42) * 0.03).to(DEV)
+    wb = (rnd(3, 3, Cin, f, seed=43) * 0.03).to(DEV)
+    bg, bb = (rnd(f, seed=44) * 0.1).to(DEV), (rnd(f, seed=45) * 0.1).to(DEV)
+    with torch.no_grad():
+        gb32 = P.conv2d_pair(a, wg, bg, wb, bb)
+        gb16 = P.conv2d_pair(a, wg, bg, wb, bb, out_dtype=mode)
+    assert gb16.dtype == mode and torch.equal(gb16, gb32.to(mode))
+    x = (rnd(B, H, H, f, seed=46) * 1.5 + 0.2).to(DEV)
+    dy = rnd(B, H, H, f, seed=47).to(DEV)
+    out = {}
+    for gb in (gb16.float(), gb16):                     # the same (representable) values in fp32 and in 16-bit storage
+        xg = x.clone().requires_grad_(True)
+        gg = gb.clone().requires_grad_(True)
+        y = P.instnorm_spade_gb(xg, gg, 0.2)
+        y.backward(dy)
+        out[gb.dtype] = (y.detach(), xg.grad, gg.grad)
+    y32, dx32, dgb32 = out[torch.float32]
+    y16, dx16, dgb16 = out[mode]
+    assert torch.equal(y16, y32) and torch.equal(dx16, dx32)
+    assert dgb16.dtype == mode and torch.equal(dgb16, dgb32.to(mode))
+    M, C = B * H * H, 2 * f
+    ws = torch.empty(N.call('mmseg_colsum_workspace_floats', M, C), device=DEV)
+    o16, o32 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    N.call('mmseg_colsum_t', dgb16, o16, ws, M, C, 0, 1 if mode == torch.bfloat16 else 2)
+    N.call('mmseg_colsum', dgb16.float(), o32, ws, M, C, 1.0, 0)
+    assert (o16 - o32).abs().max() <= 1e-5 * max(1.0, float(o32.abs().max()))
+
+
 @pytest.mark.parametrize('dt,decoder', [('bf16', 'film'), ('fp16', 'film'), ('bf16', 'spade')])
 def test_generator_step_with_16bit_trunk_storage_close_to_fp32_storage(dt, decoder):
     """conf.act_storage = 'half' at the model level: a teacher-forced DAFNet generator step with the trunk's activations and gradients
