@@ -218,12 +218,13 @@ int mmseg_instnorm_spade_fwd_gb(const float* x, const float* gb, float* y, float
                                 float act_alpha, void* stream);
 int mmseg_instnorm_spade_bwd_gb(const float* dy, const float* x, const float* stat, const float* gb, float* dx, float* dgb, float* dxn,
                                 float* ws, int B, long per_sample, int C, float eps, float act_alpha, void* stream);
-/* the same with gb / dgb stored with element code h (0 fp32, 1 bf16, 2 fp16): with 16-bit activation storage the fused gamma / beta
- * tensor and its gradient live in HBM in the 16-bit type (x, y, dy, dx stay fp32) */
-int mmseg_instnorm_spade_fwd_gb_t(const float* x, const void* gb, float* y, float* stat, float* ws, int B, long per_sample, int C, float eps,
-                                  float act_alpha, int h, void* stream);
-int mmseg_instnorm_spade_bwd_gb_t(const float* dy, const float* x, const float* stat, const void* gb, float* dx, void* dgb, float* dxn,
-                                  float* ws, int B, long per_sample, int C, float eps, float act_alpha, int h, void* stream);
+/* the same with gb / dgb stored with element code h and the output y / its gradient dy with element code hy (0 fp32, 1 bf16, 2 fp16):
+ * with 16-bit activation storage the fused gamma / beta tensor, the modulated output that feeds the next convolution and their
+ * gradients live in HBM in the 16-bit type (x and dx stay fp32) */
+int mmseg_instnorm_spade_fwd_gb_t(const float* x, const void* gb, void* y, float* stat, float* ws, int B, long per_sample, int C, float eps,
+                                  float act_alpha, int h, int hy, void* stream);
+int mmseg_instnorm_spade_bwd_gb_t(const void* dy, const float* x, const float* stat, const void* gb, float* dx, void* dgb, float* dxn,
+                                  float* ws, int B, long per_sample, int C, float eps, float act_alpha, int h, int hy, void* stream);
 /* out[c] (+)= column sums of a tensor stored with element code h (C % 64 == 0; ws: mmseg_colsum_workspace_floats(M, C) floats) */
 int mmseg_colsum_t(const void* x, float* out, float* ws, long M, int C, int accumulate, int h, void* stream);
 /* out[m] = (a[m] | b[m]) for M rows of Ca and Cb floats; da[m] += src[m][0:Ca], db[m] += src[m][Ca:]: the fused operand of two

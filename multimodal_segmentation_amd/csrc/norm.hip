@@ -434,16 +434,15 @@ __global__ void in_bwd_apply_kernel(const float* __restrict__ dxn, const float* 
 
 // ---- the same with gamma and beta as the two halves of ONE tensor gb [B*H*W][2C] (gamma = channels [0, C), beta = [C, 2C)): the
 //      output of the fused gamma + beta convolution of a SPADE unit (ops.conv2d_pair).  16-byte accesses; C % 4 == 0. ----
-template <int H>       // element code of gb: with 16-bit activation storage the fused gamma / beta tensor lives in HBM in the 16-bit type
+template <int H, int HY>       // element codes of gb and of the output y (16-bit activation storage: both live in HBM in the 16-bit type)
 __global__ void in_apply_gb_kernel(const float* __restrict__ x, const float* __restrict__ stat, const void* __restrict__ gb,
-                                   float* __restrict__ y, long per_sample, int C4, float act_alpha) {
+                                   void* __restrict__ y, long per_sample, int C4, float act_alpha) {
     const int b = blockIdx.y;
     const float mu = stat[2 * b], rs = stat[2 * b + 1];
     const long n4 = per_sample >> 2;
     const size_t off4 = (size_t)b * n4;
     const f32x4* X = reinterpret_cast<const f32x4*>(x) + off4;
     const long gb0 = 2 * (long)off4;
-    f32x4* Y = reinterpret_cast<f32x4*>(y) + off4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const long pix = i / C4;
         const int c4 = (int)(i - pix * C4);
@@ -454,12 +453,12 @@ __global__ void in_apply_gb_kernel(const float* __restrict__ x, const float* __r
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * act_alpha;
         }
-        Y[i] = v;
+        st4<HY>(y, (long)off4 + i, v);
     }
 }
 // pass 1 of the backward: dgb (dgamma | dbeta), dxn and the per-sample sums; expressions as in_bwd_partial_kernel
-template <int H>       // element code of gb AND dgb (a gradient is stored like its tensor)
-__global__ void in_bwd_partial_gb_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stat,
+template <int H, int HY>       // element codes of gb / dgb and of dy (a gradient is stored like its tensor)
+__global__ void in_bwd_partial_gb_kernel(const void* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stat,
                                          const void* __restrict__ gb, void* __restrict__ dgb, float* __restrict__ dxn_out,
                                          float* __restrict__ part, long per_sample, int nchunk, int C4, float act_alpha) {
     __shared__ float red[17];
@@ -470,7 +469,6 @@ __global__ void in_bwd_partial_gb_kernel(const float* __restrict__ dy, const flo
     const long per = (n4 + nchunk - 1) / nchunk;
     const long i0 = (long)blockIdx.x * per, i1 = min(n4, i0 + per);
     const f32x4* X = reinterpret_cast<const f32x4*>(x) + off4;
-    const f32x4* DY = reinterpret_cast<const f32x4*>(dy) + off4;
     const long gb0 = 2 * (long)off4;
     f32x4* DXN = reinterpret_cast<f32x4*>(dxn_out) + off4;
     float s1 = 0.f, s2 = 0.f;
@@ -478,7 +476,7 @@ __global__ void in_bwd_partial_gb_kernel(const float* __restrict__ dy, const flo
         const long pix = i / C4;
         const int c4 = (int)(i - pix * C4);
         const f32x4 xn = (X[i] - mu) * rs;
-        f32x4 g = DY[i];
+        f32x4 g = ld4<HY>(dy, (long)off4 + i);
         const f32x4 ga = ld4<H>(gb, gb0 + pix * 2 * C4 + c4), be = ld4<H>(gb, gb0 + pix * 2 * C4 + C4 + c4);
         f32x4 dxn, dga;
 #pragma unroll
@@ -686,38 +684,40 @@ int mmseg_instnorm_spade_bwd(const float* dy, const float* x, const float* stat,
 }
 
 // gamma and beta as the halves of one tensor gb [B * H * W][2C] (see in_apply_gb_kernel); per_sample = H * W * C; h: element code of
-// gb / dgb (0 fp32, 1 bf16, 2 fp16) -- x, y, dy, dx stay fp32
-int mmseg_instnorm_spade_fwd_gb_t(const float* x, const void* gb, float* y, float* stat, float* ws, int B, long per_sample, int C, float eps,
-                                  float act_alpha, int h, void* stream) {
-    if ((C & 3) || C <= 0 || per_sample % C != 0 || h < 0 || h > 2) return (int)hipErrorInvalidValue;
+// gb / dgb, hy: element code of the output y / of its gradient dy (0 fp32, 1 bf16, 2 fp16) -- x and dx stay fp32
+int mmseg_instnorm_spade_fwd_gb_t(const float* x, const void* gb, void* y, float* stat, float* ws, int B, long per_sample, int C, float eps,
+                                  float act_alpha, int h, int hy, void* stream) {
+    if ((C & 3) || C <= 0 || per_sample % C != 0 || h < 0 || h > 2 || hy < 0 || hy > 2 || (h && hy && h != hy)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(in_partial_kernel, dim3(IN_CHUNKS, B), dim3(256), 0, st, x, ws, per_sample, IN_CHUNKS);
     hipLaunchKernelGGL(in_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, (const float*)ws, x, stat, per_sample, IN_CHUNKS, B, eps);
     const dim3 grid(in_apply_chunks(per_sample), B);
-    if (h == 0) hipLaunchKernelGGL(in_apply_gb_kernel<0>, grid, dim3(256), 0, st, x, (const float*)stat, gb, y, per_sample, C / 4, act_alpha);
-    else if (h == 1) hipLaunchKernelGGL(in_apply_gb_kernel<1>, grid, dim3(256), 0, st, x, (const float*)stat, gb, y, per_sample, C / 4, act_alpha);
-    else hipLaunchKernelGGL(in_apply_gb_kernel<2>, grid, dim3(256), 0, st, x, (const float*)stat, gb, y, per_sample, C / 4, act_alpha);
+#define L(HH, HYY) hipLaunchKernelGGL((in_apply_gb_kernel<HH, HYY>), grid, dim3(256), 0, st, x, (const float*)stat, gb, y, per_sample, C / 4, act_alpha)
+    if (h == 0 && hy == 0) L(0, 0); else if (h == 1 && hy == 0) L(1, 0); else if (h == 2 && hy == 0) L(2, 0);
+    else if (h == 0 && hy == 1) L(0, 1); else if (h == 0 && hy == 2) L(0, 2); else if (h == 1) L(1, 1); else L(2, 2);
+#undef L
     return MMSEG_CHECK_LAUNCH();
 }
-int mmseg_instnorm_spade_bwd_gb_t(const float* dy, const float* x, const float* stat, const void* gb, float* dx, void* dgb, float* dxn,
-                                  float* ws, int B, long per_sample, int C, float eps, float act_alpha, int h, void* stream) {
-    if ((C & 3) || C <= 0 || per_sample % C != 0 || h < 0 || h > 2) return (int)hipErrorInvalidValue;
+int mmseg_instnorm_spade_bwd_gb_t(const void* dy, const float* x, const float* stat, const void* gb, float* dx, void* dgb, float* dxn,
+                                  float* ws, int B, long per_sample, int C, float eps, float act_alpha, int h, int hy, void* stream) {
+    if ((C & 3) || C <= 0 || per_sample % C != 0 || h < 0 || h > 2 || hy < 0 || hy > 2 || (h && hy && h != hy)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(IN_CHUNKS, B);
-    if (h == 0) hipLaunchKernelGGL(in_bwd_partial_gb_kernel<0>, grid, dim3(256), 0, st, dy, x, stat, gb, dgb, dxn, ws, per_sample, IN_CHUNKS, C / 4, act_alpha);
-    else if (h == 1) hipLaunchKernelGGL(in_bwd_partial_gb_kernel<1>, grid, dim3(256), 0, st, dy, x, stat, gb, dgb, dxn, ws, per_sample, IN_CHUNKS, C / 4, act_alpha);
-    else hipLaunchKernelGGL(in_bwd_partial_gb_kernel<2>, grid, dim3(256), 0, st, dy, x, stat, gb, dgb, dxn, ws, per_sample, IN_CHUNKS, C / 4, act_alpha);
+#define L(HH, HYY) hipLaunchKernelGGL((in_bwd_partial_gb_kernel<HH, HYY>), grid, dim3(256), 0, st, dy, x, stat, gb, dgb, dxn, ws, per_sample, IN_CHUNKS, C / 4, act_alpha)
+    if (h == 0 && hy == 0) L(0, 0); else if (h == 1 && hy == 0) L(1, 0); else if (h == 2 && hy == 0) L(2, 0);
+    else if (h == 0 && hy == 1) L(0, 1); else if (h == 0 && hy == 2) L(0, 2); else if (h == 1) L(1, 1); else L(2, 2);
+#undef L
     const long n = (long)B * per_sample;
     hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(in_apply_chunks(per_sample), B), dim3(256), 0, st, (const float*)dxn, x, stat, (const float*)ws, dx, per_sample, n, IN_CHUNKS, eps);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_instnorm_spade_fwd_gb(const float* x, const float* gb, float* y, float* stat, float* ws, int B, long per_sample, int C, float eps,
                                 float act_alpha, void* stream) {
-    return mmseg_instnorm_spade_fwd_gb_t(x, gb, y, stat, ws, B, per_sample, C, eps, act_alpha, 0, stream);
+    return mmseg_instnorm_spade_fwd_gb_t(x, gb, y, stat, ws, B, per_sample, C, eps, act_alpha, 0, 0, stream);
 }
 int mmseg_instnorm_spade_bwd_gb(const float* dy, const float* x, const float* stat, const float* gb, float* dx, float* dgb, float* dxn,
                                 float* ws, int B, long per_sample, int C, float eps, float act_alpha, void* stream) {
-    return mmseg_instnorm_spade_bwd_gb_t(dy, x, stat, gb, dx, dgb, dxn, ws, B, per_sample, C, eps, act_alpha, 0, stream);
+    return mmseg_instnorm_spade_bwd_gb_t(dy, x, stat, gb, dx, dgb, dxn, ws, B, per_sample, C, eps, act_alpha, 0, 0, stream);
 }
 
 }  // extern "C"

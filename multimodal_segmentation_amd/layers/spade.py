@@ -51,7 +51,10 @@ def _spade(m, name, anatomy_input, layer, act_alpha):
     import torch
     half = ops.act16_dtype()
     gb = nn.conv_pair(m, name + '_gamma', name + '_beta', a, out_dtype=half if half is not None else torch.float32)
-    return ops.instnorm_spade_gb(layer, gb, act_alpha)
+    # the modulated output feeds a convolution (c0 / c1 / cs): stored in 16 bits too when that convolution can read it (MFMA fast path:
+    # input channels a multiple of 32); the unit's INPUT (a convolution output / the up-sampled trunk) stays fp32
+    y_dt = half if (half is not None and layer.shape[-1] % 32 == 0) else torch.float32
+    return ops.instnorm_spade_gb(layer, gb, act_alpha, out_dtype=y_dt)
 
 
 def spade_block(m, n, anatomy_input, layer, fin, fout):

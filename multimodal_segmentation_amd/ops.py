@@ -1025,15 +1025,15 @@ class _InstNormSpadeGB(torch.autograd.Function):
     """instnorm_spade with gamma and beta as the halves of one tensor gb [B, H, W, 2C] (the output of conv2d_pair)"""
 
     @staticmethod
-    def forward(ctx, x, gb, act_alpha):
+    def forward(ctx, x, gb, act_alpha, out_dtype=torch.float32):
         x, gb = _c(x), _c(gb)
         B, C = x.shape[0], x.shape[-1]
         assert gb.shape == x.shape[:-1] + (2 * C,)
         per = x.numel() // B
-        y = _new(x.shape, x)
+        y = _new(x.shape, x, out_dtype)
         stat = _new((B, 2), x)
         ws = _ws('instnorm', N.call('mmseg_in_workspace_floats', B), x.device)
-        N.call('mmseg_instnorm_spade_fwd_gb_t', x, gb, y, stat, ws, B, per, C, IN_EPS, float(act_alpha), _h(gb))
+        N.call('mmseg_instnorm_spade_fwd_gb_t', x, gb, y, stat, ws, B, per, C, IN_EPS, float(act_alpha), _h(gb), _h(y))
         ctx.act_alpha = act_alpha
         ctx.save_for_backward(x, stat, gb)
         return y
@@ -1046,13 +1046,14 @@ class _InstNormSpadeGB(torch.autograd.Function):
         dx, dgb = _new(x.shape, x), _new(gb.shape, gb, gb.dtype)          # a gradient is stored like its tensor
         dxn = _ws('instnorm_dxn', x.numel(), x.device)
         ws = _ws('instnorm', N.call('mmseg_in_workspace_floats', B), x.device)
-        N.call('mmseg_instnorm_spade_bwd_gb_t', _c(dy), x, stat, gb, dx, dgb, dxn, ws, B, per, C, IN_EPS, float(ctx.act_alpha), _h(gb))
-        return dx, dgb, None
+        dy = _c(dy)
+        N.call('mmseg_instnorm_spade_bwd_gb_t', dy, x, stat, gb, dx, dgb, dxn, ws, B, per, C, IN_EPS, float(ctx.act_alpha), _h(gb), _h(dy))
+        return dx, dgb, None, None
 
 
-def instnorm_spade_gb(x, gb, act_alpha=-1.0):
-    """act( IN(x) * (1 + gb[..., :C]) + gb[..., C:] )"""
-    return _InstNormSpadeGB.apply(x, gb, act_alpha)
+def instnorm_spade_gb(x, gb, act_alpha=-1.0, out_dtype=torch.float32):
+    """act( IN(x) * (1 + gb[..., :C]) + gb[..., C:] ); `out_dtype`: storage type of the result (and of its gradient)"""
+    return _InstNormSpadeGB.apply(x, gb, act_alpha, out_dtype)
 
 
 class _ExpandScalar(torch.autograd.Function):

@@ -439,13 +439,16 @@ def instnorm_spade_bwd_gb(dy, x, stat, gb, dx, dgb, dxn, ws, B, per, C, eps, act
     return rc
 
 
-def instnorm_spade_fwd_gb_t(x, gb, y, stat, ws, B, per, C, eps, act_alpha, h):
-    return instnorm_spade_fwd_gb(x, gb.float(), y, stat, ws, B, per, C, eps, act_alpha)
+def instnorm_spade_fwd_gb_t(x, gb, y, stat, ws, B, per, C, eps, act_alpha, h, hy):
+    tmp = torch.empty(y.shape, dtype=torch.float32)
+    rc = instnorm_spade_fwd_gb(x, gb.float(), tmp, stat, ws, B, per, C, eps, act_alpha)
+    y.copy_(tmp.to(y.dtype))
+    return rc
 
 
-def instnorm_spade_bwd_gb_t(dy, x, stat, gb, dx, dgb, dxn, ws, B, per, C, eps, act_alpha, h):
+def instnorm_spade_bwd_gb_t(dy, x, stat, gb, dx, dgb, dxn, ws, B, per, C, eps, act_alpha, h, hy):
     tmp = torch.empty(dgb.shape, dtype=torch.float32)
-    rc = instnorm_spade_bwd_gb(dy, x, stat, gb.float(), dx, tmp, dxn, ws, B, per, C, eps, act_alpha)
+    rc = instnorm_spade_bwd_gb(dy.float(), x, stat, gb.float(), dx, tmp, dxn, ws, B, per, C, eps, act_alpha)
     dgb.copy_(tmp.to(dgb.dtype))
     return rc
 

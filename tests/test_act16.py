@@ -230,6 +230,7 @@ def test_spade_gamma_beta_tensor_in_16_bits(mode):
     x = (rnd(B, H, H, f, seed=46) * 1.5 + 0.2).to(DEV)
     dy = rnd(B, H, H, f, seed=47).to(DEV)
     out = {}
+    dy = dy.to(mode).float()                            # a cotangent that is representable in 16 bits
     for gb in (gb16.float(), gb16):                     # the same (representable) values in fp32 and in 16-bit storage
         xg = x.clone().requires_grad_(True)
         gg = gb.clone().requires_grad_(True)
@@ -240,6 +241,14 @@ def test_spade_gamma_beta_tensor_in_16_bits(mode):
     y16, dx16, dgb16 = out[mode]
     assert torch.equal(y16, y32) and torch.equal(dx16, dx32)
     assert dgb16.dtype == mode and torch.equal(dgb16, dgb32.to(mode))
+    # ... and with the OUTPUT (and its incoming gradient) stored in 16 bits as well: y is the rounding of the fp32 y, the gradients are
+    # those of the fp32-storage call (the cotangent is representable)
+    xg = x.clone().requires_grad_(True)
+    gg = gb16.clone().requires_grad_(True)
+    yh = P.instnorm_spade_gb(xg, gg, 0.2, out_dtype=mode)
+    assert yh.dtype == mode and torch.equal(yh, y32.to(mode))
+    yh.backward(dy.to(mode))
+    assert torch.equal(xg.grad, dx32) and torch.equal(gg.grad, dgb16)
     M, C = B * H * H, 2 * f
     ws = torch.empty(N.call('mmseg_colsum_workspace_floats', M, C), device=DEV)
     o16, o32 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
