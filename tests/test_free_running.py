@@ -75,9 +75,9 @@ def _build(H, B, seed=10):
 
 
 def _oracle_state(orc):
-    W = {k: v.detach().double().numpy() for k, v in orc.P.items()}
-    A = {key: (ad.t, {k: v.detach().double().numpy() for k, v in ad.m.items()},
-               {k: v.detach().double().numpy() for k, v in ad.v.items()}) for key, ad in orc.adam.items()}
+    W = {k: v.detach().double().cpu().numpy() for k, v in orc.P.items()}
+    A = {key: (ad.t, {k: v.detach().double().cpu().numpy() for k, v in ad.m.items()},
+               {k: v.detach().double().cpu().numpy() for k, v in ad.v.items()}) for key, ad in orc.adam.items()}
     return W, A
 
 
@@ -159,7 +159,7 @@ def compare_states(model, orc, lr_of, report=None, trainers=None):
 def _anatomy_flips(model, orc):
     n = 0
     for key in ('s1', 's2'):
-        n += int((model.last_factors[key].detach().cpu().numpy() != orc.last_outputs[key].numpy()).sum())
+        n += int((model.last_factors[key].detach().cpu().numpy() != orc.last_outputs[key].cpu().numpy()).sum())
     return n
 
 
@@ -183,7 +183,7 @@ def _check(worst, flips, tag, bars=None):
 
 
 def _pool_diff(p, o):
-    p, o = p.detach().float().cpu().numpy(), o.detach().float().numpy()
+    p, o = p.detach().float().cpu().numpy(), o.detach().float().cpu().numpy()
     return float((np.abs(p - o) > 1e-3).mean()), float(np.abs(p - o).max())
 
 
@@ -195,8 +195,8 @@ def synced_iteration(model, ex, orc, d, lines, tag, gen_bars=None):
     O(lr) weight differences that the next phase would be charged with."""
     dev = lambda a: nn.to_device(a, model.D_Mask.device)
     sel = lambda pool, idx: pool.index_select(0, torch.as_tensor(np.asarray(idx), dtype=torch.long, device=pool.device))
-    t = Hh.to_torch(d, torch.float32)
-    keep = lambda key: (lambda k: True)
+    odev = next(iter(orc.P.values())).device              # (the oracle's tensors may live on another device: tools/trajectory_parity.py)
+    t = {k: v.to(odev) for k, v in Hh.to_torch(d, torch.float32).items()}
 
     def phase(name, keys, flips=0, bars=None):
         sub = []
