@@ -893,7 +893,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
     // tap t (two register sets, the loop advances two taps per trip).  Measured: neither this prefetch nor the packed FMAs move
     // the kernel (1.91 -> 1.88 ms per iteration, 2.9 TB/s of algorithmic bytes = 52 TFLOP/s, i.e. 75 % of the UNPACKED fp32 VALU
     // rate): PMC shows 485 VALU instructions per wave and a launch time of exactly 288 x 8 + 197 x 4 cycles per wave -- the packed
-    // FMA with an SGPR-pair / op_sel operand issues at half rate, the kernel is VALU-bound.
+    // FMA issues at half rate here, the kernel is VALU-bound.  The weights as VGPR pairs (staged once per block
+    // in LDS, broadcast reads per tap) instead of SGPR pairs: measured 1.95 ms, no better -- it is not the scalar operand.
     auto fetch = [&](int t, f32x4 (&xv)[CIN / 4]) {
         const int kh = t / KS, kw = t - kh * KS;
         const int hi = hq + kh - pad, wi = wq + kw - pad;
