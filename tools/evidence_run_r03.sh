@@ -6,7 +6,7 @@ cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_f32.json 2> $O/bench_f32.err
 echo bench done
 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o b -- python3 $R/bench.py --no-cpu-baseline --no-multi-stream-region --steps 7 --warmup 3 > $O/trace_bench.json 2> $O/trace_bench.err
-rocprofv3 --kernel-trace --output-format csv -d $O/trace_spade_bf16_act16 -o b -- python3 $R/bench.py --no-cpu-baseline --no-multi-stream --decoder spade --dtype bf16 --act16 --steps 4 --warmup 3 > $O/trace_spade_bf16_act16_bench.json 2> $O/trace_spade_bf16_act16_bench.err
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_spade_bf16_act16 -o b -- python3 $R/bench.py --no-cpu-baseline --no-multi-stream --no-multi-stream-region --decoder spade --dtype bf16 --act16 --steps 4 --warmup 3 > $O/trace_spade_bf16_act16_bench.json 2> $O/trace_spade_bf16_act16_bench.err
 echo traces done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --no-cpu-baseline --no-conv-timer --no-multi-stream-region --steps 2 --warmup 1 > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --no-cpu-baseline --no-conv-timer --no-multi-stream-region --steps 2 --warmup 1 > /dev/null 2> $O/pmc_write.err
