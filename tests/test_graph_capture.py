@@ -24,7 +24,9 @@ def _state(models):
     return [w.copy() for m in models for w in m.get_weights()]
 
 
-@pytest.mark.parametrize('extra', [{}, {'compute_dtype': 'bf16', 'act_storage': 'half'}], ids=['fp32', 'bf16-act16'])
+@pytest.mark.parametrize('extra', [{}, {'compute_dtype': 'bf16', 'act_storage': 'half'},
+                                   {'compute_dtype': 'bf16', 'act_storage': 'half', 'decoder': 'spade'}],
+                         ids=['fp32', 'bf16-act16', 'spade-bf16-act16'])
 def test_discriminator_and_generator_steps_replayed_from_graphs_are_bitwise_the_eager_steps(extra):
     from multimodal_segmentation_amd import ops as P
     from tests import helpers as Hh
