@@ -12,7 +12,6 @@ Weights are NOT autograd leaves: the autograd tape only carries activation gradi
 weight gradients straight into the gradient arena.
 """
 import math
-import os
 from collections import OrderedDict
 
 import numpy as np
