@@ -323,7 +323,11 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # the data-parallel branch runs whenever there is more than one rank; MMSEG_BENCH_FORCE_DIST=1 sends a ONE-rank run (under the same
+    # launcher) through it too -- RCCL process group, broadcast, gradient all-reduces, replica check -- which is how the 1-GPU test box
+    # rehearses the multi-GPU run (tests/test_bench_cli.py)
+    distributed = world > 1 or os.environ.get('MMSEG_BENCH_FORCE_DIST') == '1'
+    if distributed:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
@@ -377,8 +381,8 @@ def main():
         DAFNet, DAFNetExecutor = MMSDNet, MMSDNetExecutor
     model = DAFNet(conf)
     model.build()
-    dp.enable(world > 1)
-    if world > 1:
+    dp.enable(distributed, force=distributed and world == 1)        # one forced rank: the all-reduces still run (identity)
+    if distributed:
         all_models = model._generator_models() + [d for d in (model.D_Mask, getattr(model, 'D_Image1', None),
                                                              getattr(model, 'D_Image2', None)) if d is not None]
         dp.broadcast_models(all_models)
@@ -401,7 +405,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
 
     _progress('warmup')
@@ -425,7 +429,7 @@ def main():
     dp_counters = dp.counters()
     per_rank_ms = [1000.0 * dt / args.steps]
     replicas_ok = None
-    if world > 1:
+    if distributed:
         mine = torch.tensor([dt], device='cuda')
         allt = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allt, mine)
@@ -446,7 +450,7 @@ def main():
     # HIP streams, bit-identical results.  Kept out of the headline because per-kernel elapsed times of time-shared kernels would
     # misstate the `roofline` entries.
     multi = None
-    if args.model == 'dafnet' and not args.multi_stream and not args.graphs and not args.no_multi_stream_region and world == 1:
+    if args.model == 'dafnet' and not args.multi_stream and not args.graphs and not args.no_multi_stream_region and not distributed:
         conf['multi_stream'] = True
         for _ in range(2):
             ex.train_batch(losses)
@@ -467,8 +471,8 @@ def main():
     line = {
         'metric': '2D slices/sec %s train step, %dx%dx2-modality bs=%d/GPU' % ('DAFNet' if args.model == 'dafnet' else 'MMSDNet',
                                                                                 H, H, args.batch),
-        'value': value, 'unit': 'paired slices/s', 'n_gpus': (dist.get_world_size() if world > 1 else 1),
-        'rccl_ranks': (dist.get_world_size() if world > 1 else 0), 'steps': args.steps, 'warmup': args.warmup,
+        'value': value, 'unit': 'paired slices/s', 'n_gpus': (dist.get_world_size() if distributed else 1),
+        'rccl_ranks': (dist.get_world_size() if distributed else 0), 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'DAFNet-%s (dafnet%s_config_chaos) %dx%d 2-modality training iteration: generator fit + '
@@ -489,7 +493,7 @@ def main():
         line['conv_roofline_frac_whole_step'] = TFLOP_PER_PAIR[key] * value / world / (
             BF16_MFMA_PEAK_TFLOPS if args.dtype in ('bf16', 'f16') else FP32_MFMA_PEAK_TFLOPS)
     line['per_rank_ms_per_step'] = per_rank_ms
-    if world > 1:
+    if distributed:
         st = max(dp_counters['steps'], 1)
         line['dp'] = {'trainer_steps': dp_counters['steps'], 'collectives_per_iteration': dp_counters['collectives'] / float(args.steps),
                       'overlapped_with_backward_per_iteration': dp_counters['overlapped'] / float(args.steps),
@@ -553,11 +557,19 @@ def main():
             line['roofline_family'] = fam
         if multi is not None:
             line['multi_stream'] = multi
+        # share of the timed window with a kernel running, from the rocprofv3 kernel trace of THIS command committed under profiles/
+        # (tools/gpu_busy.py; like `traffic` it cannot be measured from inside the process without timing every launch)
+        bpath = os.path.join(ROOT, 'profiles', 'r03_gpu_busy_bench_%s_%s_%d_bs%d.txt' % (args.model, args.decoder, H, args.batch))
+        if args.dtype == 'f32' and args.l_mix == 1.0 and not args.graphs and not args.multi_stream and os.path.exists(bpath):
+            import re
+            m = re.search(r'= ([0-9.]+) % GPU-busy', open(bpath).read())
+            if m:
+                line['gpu_busy_frac'] = {'value': float(m.group(1)) / 100.0, 'source': os.path.relpath(bpath, ROOT) + ' (rocprofv3 --kernel-trace of this command)'}
         if world == 1 and not args.no_cpu_baseline and args.model == 'dafnet':
             _progress('cpu baseline (oracle, bounded sample)')
             line['cpu_baseline'] = cpu_baseline(H, args.decoder, args.batch)
         print(json.dumps(line))
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
