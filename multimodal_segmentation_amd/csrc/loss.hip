@@ -45,20 +45,34 @@ __global__ void segloss_partial_kernel(const float* __restrict__ pred, const flo
     }
 }
 // stats: [B][3] then [2][SEG_MAXC] class sums (summed over the local batch)
-__global__ void segloss_stats_final_kernel(const float* __restrict__ part, float* __restrict__ stats, int B) {
-    const int t = threadIdx.x;
+// block 1024 = 64 outputs x 16 lanes: a lane walks every 16th chunk partial, then a fixed-order sum over the lanes
+// (one thread per output walked up to B * LOSS_CHUNKS partials with dependent loads: 31 us)
+__global__ __launch_bounds__(1024) void segloss_stats_final_kernel(const float* __restrict__ part, float* __restrict__ stats, int B) {
+    __shared__ float sm[16][65];
     const int W = 3 + 2 * SEG_MAXC;
-    if (t < B * 3) {
-        const int b = t / 3, k = t % 3;
+    const int ln = threadIdx.x & 15;
+    const int nout = B * 3 + 2 * SEG_MAXC;
+    for (int base = 0; base < nout; base += 64) {
+        const int t = base + (threadIdx.x >> 4);
         float a = 0.f;
-        for (int ch = 0; ch < LOSS_CHUNKS; ++ch) a += part[((size_t)b * LOSS_CHUNKS + ch) * W + k];
-        stats[t] = a;
-    }
-    if (t < 2 * SEG_MAXC) {
-        float a = 0.f;
-        for (int b = 0; b < B; ++b)
-            for (int ch = 0; ch < LOSS_CHUNKS; ++ch) a += part[((size_t)b * LOSS_CHUNKS + ch) * W + 3 + t];
-        stats[B * 3 + t] = a;
+        if (t < B * 3) {
+            const int b = t / 3, k = t % 3;
+#pragma unroll 8
+            for (int ch = ln; ch < LOSS_CHUNKS; ch += 16) a += part[((size_t)b * LOSS_CHUNKS + ch) * W + k];
+        } else if (t < nout) {
+            const int k = t - B * 3;
+#pragma unroll 8
+            for (int q = ln; q < B * LOSS_CHUNKS; q += 16) a += part[(size_t)q * W + 3 + k];
+        }
+        sm[ln][threadIdx.x >> 4] = a;
+        __syncthreads();
+        if (ln == 0 && t < nout) {
+            float v = 0.f;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) v += sm[l][threadIdx.x >> 4];
+            stats[t] = v;
+        }
+        __syncthreads();
     }
 }
 // loss value + gradient coefficients.  n_pix_global: pixel count of the WHOLE (all-rank) batch, normalises the loss value;

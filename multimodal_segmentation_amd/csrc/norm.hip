@@ -122,30 +122,33 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
     }
 }
 
-// sum the per-block partials of 64 channels with 4 lanes per channel (blockDim 256); result valid where lane == 0
-__device__ __forceinline__ void reduce_partials_64x4(const float* __restrict__ part, int nblk, int C, int c, int lane,
-                                                     float& s1, float& s2, float* sm /* 512 floats */) {
+// sum the per-block partials of 64 channels with FIN_LPC lanes per channel (blockDim FIN_NT); result valid where lane == 0.  (Four
+// lanes per channel walked up to 128 partials each with dependent loads: ~10.7 us per launch, 104 launches per training iteration.)
+constexpr int FIN_LPC = 16, FIN_NT = 64 * FIN_LPC;
+__device__ __forceinline__ void reduce_partials_64(const float* __restrict__ part, int nblk, int C, int c, int lane,
+                                                   float& s1, float& s2, float* sm /* 2 * FIN_NT floats */) {
     float a1 = 0.f, a2 = 0.f;
     if (c < C) {
-#pragma unroll 4
-        for (int b = lane; b < nblk; b += 4) { a1 += part[((size_t)b * 2) * C + c]; a2 += part[((size_t)b * 2 + 1) * C + c]; }
+#pragma unroll 8
+        for (int b = lane; b < nblk; b += FIN_LPC) { a1 += part[((size_t)b * 2) * C + c]; a2 += part[((size_t)b * 2 + 1) * C + c]; }
     }
-    sm[threadIdx.x] = a1; sm[256 + threadIdx.x] = a2;
+    sm[threadIdx.x] = a1; sm[FIN_NT + threadIdx.x] = a2;
     __syncthreads();
     const int cl = threadIdx.x & 63;
-    s1 = sm[cl] + sm[64 + cl] + sm[128 + cl] + sm[192 + cl];
-    s2 = sm[256 + cl] + sm[320 + cl] + sm[384 + cl] + sm[448 + cl];
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int l = 0; l < FIN_LPC; ++l) { s1 += sm[l * 64 + cl]; s2 += sm[FIN_NT + l * 64 + cl]; }     // fixed order
 }
 
-// training statistics -> mean, invstd, fused scale/shift, moving-average update.  grid = ceil(C/64), block 256
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x, const float* __restrict__ gamma,
+// training statistics -> mean, invstd, fused scale/shift, moving-average update.  grid = ceil(C/64), block FIN_NT
+__global__ __launch_bounds__(FIN_NT) void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,
                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mov_mean,
                                       float* __restrict__ mov_var, int nblk, int C, long M, float eps, float momentum) {
-    __shared__ float sm[512];
+    __shared__ float sm[2 * FIN_NT];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     float s1, s2;
-    reduce_partials_64x4(part, nblk, C, c, lane, s1, s2, sm);
+    reduce_partials_64(part, nblk, C, c, lane, s1, s2, sm);
     if (c >= C || lane != 0) return;
     const float invM = 1.f / (float)M;
     const float d = s1 * invM;
@@ -165,12 +168,12 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ part, const floa
 
 // ---- synchronised BatchNorm across data-parallel ranks (optional; parallel/dp.py) -------------------------------------------
 // Local half of the statistics: per-channel mean and BIASED variance of this rank's rows -> stat2 [2][C].
-__global__ void bn_stats_local_final_kernel(const float* __restrict__ part, const float* __restrict__ x, float* __restrict__ stat2,
+__global__ __launch_bounds__(FIN_NT) void bn_stats_local_final_kernel(const float* __restrict__ part, const float* __restrict__ x, float* __restrict__ stat2,
                                             int nblk, int C, long M) {
-    __shared__ float sm[512];
+    __shared__ float sm[2 * FIN_NT];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     float s1, s2;
-    reduce_partials_64x4(part, nblk, C, c, lane, s1, s2, sm);
+    reduce_partials_64(part, nblk, C, c, lane, s1, s2, sm);
     if (c >= C || lane != 0) return;
     const float invM = 1.f / (float)M;
     const float d = s1 * invM;
@@ -207,11 +210,11 @@ __global__ void bn_stats_combine_kernel(const float* __restrict__ gathered, int 
     }
 }
 // backward sums of this rank -> sums [2][C] = (sum g, sum g * xhat)
-__global__ void bn_bwd_sums_final_kernel(const float* __restrict__ part, float* __restrict__ sums, int nblk, int C) {
-    __shared__ float sm[512];
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_sums_final_kernel(const float* __restrict__ part, float* __restrict__ sums, int nblk, int C) {
+    __shared__ float sm[2 * FIN_NT];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     float s1, s2;
-    reduce_partials_64x4(part, nblk, C, c, lane, s1, s2, sm);
+    reduce_partials_64(part, nblk, C, c, lane, s1, s2, sm);
     if (c >= C || lane != 0) return;
     sums[c] = s1; sums[C + c] = s2;
 }
@@ -274,13 +277,13 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 }
 
 // finalize backward sums: dbeta, dgamma and per-channel coefficients  dx = A*g + Bc*x + Cc
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ mean,
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                     float* __restrict__ coef /* [3][C] */, int nblk, int C, long M, int accumulate) {
-    __shared__ float sm[512];
+    __shared__ float sm[2 * FIN_NT];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     float s1, s2;
-    reduce_partials_64x4(part, nblk, C, c, lane, s1, s2, sm);
+    reduce_partials_64(part, nblk, C, c, lane, s1, s2, sm);
     if (c >= C || lane != 0) return;
     if (accumulate) { dbeta[c] += s1; dgamma[c] += s2; }      // straight into the gradient arena
     else { dbeta[c] = s1; dgamma[c] = s2; }
@@ -533,7 +536,7 @@ int mmseg_bn_stats(const float* x, const float* gamma, const float* beta, float*
         hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, ws, M, C, rpb, 0);
     }
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, x, gamma, beta, mean, invstd,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(FIN_NT), 0, st, (const float*)ws, x, gamma, beta, mean, invstd,
                        scale, shift, mov_mean, mov_var, nblk, C, M, eps, momentum);
     return MMSEG_CHECK_LAUNCH();
 }
@@ -558,7 +561,7 @@ static int bn_launch_partial(int mode, const float* x, const float* dy, const fl
 int mmseg_bn_stats_local(const float* x, float* stat2, float* ws, long M, int C, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int nblk = bn_launch_partial(0, x, nullptr, nullptr, nullptr, nullptr, ws, M, C, 0, st);
-    hipLaunchKernelGGL(bn_stats_local_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, x, stat2, nblk, C, M);
+    hipLaunchKernelGGL(bn_stats_local_final_kernel, dim3((C + 63) / 64), dim3(FIN_NT), 0, st, (const float*)ws, x, stat2, nblk, C, M);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_bn_stats_combine(const float* gathered, int R, const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
@@ -572,7 +575,7 @@ int mmseg_bn_bwd_sums(const float* dy, const float* y, const float* x, const flo
                       long M, int C, int relu, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int nblk = bn_launch_partial(1, x, dy, y, mean, invstd, ws, M, C, relu, st);
-    hipLaunchKernelGGL(bn_bwd_sums_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, sums, nblk, C);
+    hipLaunchKernelGGL(bn_bwd_sums_final_kernel, dim3((C + 63) / 64), dim3(FIN_NT), 0, st, (const float*)ws, sums, nblk, C);
     return MMSEG_CHECK_LAUNCH();
 }
 // dgamma / dbeta (may be NULL) <- local sums; coef [3][C] <- global sums and M_total; then dx = mmseg_bn_bwd_apply
@@ -621,7 +624,7 @@ int mmseg_bn_bwd(const float* dy, const float* y, const float* x, const float* g
         const long rpb = (M + nblk - 1) / nblk;
         hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu);
     }
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M, accumulate);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(FIN_NT), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M, accumulate);
     const long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y, x, (const float*)coef, dx, n4, C / 4, relu);
     return MMSEG_CHECK_LAUNCH();
@@ -644,7 +647,7 @@ int mmseg_bn_bwd_x(const float* dy, const float* x, const float* scale, const fl
         const long rpb = (M + nblk - 1) / nblk;
         hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(256), 0, st, x, dy, none, mean, invstd, ws, M, C, rpb, relu, scale, shift);
     }
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M, accumulate);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(FIN_NT), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta, coef, nblk, C, M, accumulate);
     const long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, none, x, (const float*)coef, dx, n4, C / 4, relu, scale, shift);
     return MMSEG_CHECK_LAUNCH();

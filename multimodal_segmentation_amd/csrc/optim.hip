@@ -39,7 +39,8 @@ __global__ void spec_gemv_t_kernel(const float* __restrict__ w, const float* __r
     if (n >= N) return;
     const int k0 = blockIdx.y * kper, k1 = min(K, k0 + kper);
     float a = 0.f;
-    for (int k = k0; k < k1; ++k) a += w[(size_t)k * N + n] * u[k];
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) a += w[(size_t)k * N + n] * u[k];          // (unrolled: 8 independent row loads in flight, same summation order)
     part[(size_t)blockIdx.y * N + n] = a;
 }
 // out[k] = sum_n W[k][n] * v[n]  (one wave per row)
@@ -118,7 +119,8 @@ __global__ void spec_gemv_t_multi_kernel(SpecBatch b, int first) {
     const int kper = (K + SPEC_KS - 1) / SPEC_KS;
     const int k0 = blockIdx.y * kper, k1 = min(K, k0 + kper);
     float a = 0.f;
-    for (int k = k0; k < k1; ++k) a += w[(size_t)k * N + n] * u[k];
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) a += w[(size_t)k * N + n] * u[k];          // (unrolled: 8 independent row loads in flight, same summation order)
     part[(size_t)blockIdx.y * N + n] = a;
 }
 __global__ void spec_gemv_n_multi_kernel(SpecBatch b) {

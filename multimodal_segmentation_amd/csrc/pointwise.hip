@@ -226,6 +226,27 @@ __global__ void film_fwd_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
+// C % 4 == 0, 16-byte aligned tensors: one float4 of channels per thread step, grid.y = sample (no 64-bit divisions)
+__global__ __launch_bounds__(256) void film_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ res, float* __restrict__ y, int n4_per_sample, int C4, float alpha) {
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * n4_per_sample;
+    const f32x4* X = reinterpret_cast<const f32x4*>(x) + base;
+    const f32x4* R = res ? reinterpret_cast<const f32x4*>(res) + base : nullptr;
+    f32x4* Y = reinterpret_cast<f32x4*>(y) + base;
+    const f32x4* G = reinterpret_cast<const f32x4*>(gamma) + (size_t)b * C4;
+    const f32x4* Bt = reinterpret_cast<const f32x4*>(beta) + (size_t)b * C4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4_per_sample; i += gridDim.x * 256) {
+        const int c4 = i % C4;
+        const f32x4 xv = X[i], ga = G[c4], be = Bt[c4];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = xv[e] * ga[e] + be[e]; v[e] = t >= 0.f ? t : t * alpha; }
+        if (R) v += R[i];
+        Y[i] = v;
+    }
+}
+
 // backward of u = leaky(x*gamma+beta): given du, x, gamma, beta ->
 //   dx = g*gamma,  part_dgamma[blk][b][c] = sum g*x,  part_dbeta = sum g   with g = du * leaky'(x*gamma+beta)
 __global__ void film_bwd_kernel(const float* __restrict__ du, const float* __restrict__ x, const float* __restrict__ gamma,
@@ -257,17 +278,68 @@ __global__ void film_bwd_kernel(const float* __restrict__ du, const float* __res
     }
 }
 
-__global__ void film_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                      int B, int C, int nchunk) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i % C;
-    float tg = 0.f, tb = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
-        const float* o = part + ((size_t)k * B + b) * 2 * C;
-        tg += o[c]; tb += o[C + c];
+// the same with one float4 of channels per thread (C % 4 == 0, 256 % (C / 4) == 0, 16-byte aligned tensors); the block's partial sums
+// meet in LDS and are folded by a fixed-order tree over the pixel lanes
+__global__ __launch_bounds__(256) void film_bwd_v4_kernel(const float* __restrict__ du, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ part,
+                                                          int B, int HW, int C, float alpha, int nchunk) {
+    __shared__ f32x4 sm[2][256];
+    const int b = blockIdx.y, tid = threadIdx.x, C4 = C >> 2;
+    const int c4 = tid % C4, pl = tid / C4, npl = 256 / C4;
+    const int per = (HW + nchunk - 1) / nchunk;
+    const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[b * C4 + c4], be = reinterpret_cast<const f32x4*>(beta)[b * C4 + c4];
+    const size_t base = (size_t)b * HW * C4;
+    const f32x4* X = reinterpret_cast<const f32x4*>(x) + base;
+    const f32x4* DU = reinterpret_cast<const f32x4*>(du) + base;
+    f32x4* DX = reinterpret_cast<f32x4*>(dx) + base;
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int px = p0 + pl; px < p1; px += npl) {
+        const int i = px * C4 + c4;
+        const f32x4 xv = X[i], d = DU[i];
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float pre = xv[e] * ga[e] + be[e]; g[e] = d[e] * (pre >= 0.f ? 1.f : alpha); }
+        DX[i] = g * ga;
+        sg += g * xv; sb += g;
     }
-    dgamma[i] = tg; dbeta[i] = tb;
+    sm[0][tid] = sg; sm[1][tid] = sb;
+    __syncthreads();
+    for (int st = npl >> 1; st >= 1; st >>= 1) {             // npl is a power of two (256 / C4 with C4 a power of two) or handled below
+        if (pl < st) { sm[0][tid] += sm[0][tid + st * C4]; sm[1][tid] += sm[1][tid + st * C4]; }
+        __syncthreads();
+    }
+    if (tid < C4) {
+        float* o = part + ((size_t)blockIdx.x * B + b) * 2 * C;
+        *reinterpret_cast<f32x4*>(o + 4 * tid) = sm[0][tid];
+        *reinterpret_cast<f32x4*>(o + C + 4 * tid) = sm[1][tid];
+    }
+}
+
+// 16 lanes per (b, c) walk the chunk partials (8 each at 128 chunks), then a fixed-order sum over the lanes; block 256 = 16 pairs
+__global__ __launch_bounds__(256) void film_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int B, int C, int nchunk) {
+    __shared__ float sm[2][16][17];
+    const int pl = threadIdx.x & 15, ln = threadIdx.x >> 4;          // consecutive threads = consecutive channels: coalesced reads
+    const int i = blockIdx.x * 16 + pl;
+    float tg = 0.f, tb = 0.f;
+    if (i < B * C) {
+        const int b = i / C, c = i % C;
+#pragma unroll 4
+        for (int k = ln; k < nchunk; k += 16) {
+            const float* o = part + ((size_t)k * B + b) * 2 * C;
+            tg += o[c]; tb += o[C + c];
+        }
+    }
+    sm[0][ln][pl] = tg; sm[1][ln][pl] = tb;
+    __syncthreads();
+    if (ln == 0 && i < B * C) {
+        float g = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) { g += sm[0][l][pl]; bsum += sm[1][l][pl]; }
+        dgamma[i] = g; dbeta[i] = bsum;
+    }
 }
 
 // ---- element-wise maximum (tf.maximum gradient rule: ties go to the FIRST argument) -----------------------
@@ -531,9 +603,16 @@ int mmseg_softmax_bwd(const float* dy, const float* p, float* dx, long npix, int
     return MMSEG_CHECK_LAUNCH();
 }
 
+static inline bool film_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int mmseg_film_fwd(const float* x, const float* gamma, const float* beta, const float* res, float* y, int B, long HW, int C,
                    float alpha, void* stream) {
     const long n = (long)B * HW * C;
+    const long n4s = HW * (C / 4);
+    if (C % 4 == 0 && n4s < (1L << 30) && B <= 65535 && film_al16(x) && film_al16(y) && film_al16(gamma) && film_al16(beta) && (res == nullptr || film_al16(res))) {
+        long gx = (n4s + 255) / 256; if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(film_fwd_v4_kernel, dim3((unsigned)gx, B), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, res, y, (int)n4s, C / 4, alpha);
+        return MMSEG_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(film_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, res, y, B, HW, C, alpha);
     return MMSEG_CHECK_LAUNCH();
 }
@@ -543,8 +622,13 @@ int mmseg_film_bwd(const float* du, const float* x, const float* gamma, const fl
                    float* ws, int B, long HW, int C, float alpha, void* stream) {
     if (C > 256 || 256 % C != 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(film_bwd_kernel, dim3(FILM_CHUNKS, B), dim3(256), 2 * 256 * sizeof(float), st, du, x, gamma, beta, dx, ws, B, HW, C, alpha, FILM_CHUNKS);
-    hipLaunchKernelGGL(film_bwd_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, (const float*)ws, dgamma, dbeta, B, C, FILM_CHUNKS);
+    const int C4 = C / 4;
+    if (C % 4 == 0 && (C4 & (C4 - 1)) == 0 && HW * (long)C4 < (1L << 30) && film_al16(du) && film_al16(x) && film_al16(dx) && film_al16(gamma) &&
+        film_al16(beta) && film_al16(ws))
+        hipLaunchKernelGGL(film_bwd_v4_kernel, dim3(FILM_CHUNKS, B), dim3(256), 0, st, du, x, gamma, beta, dx, ws, B, (int)HW, C, alpha, FILM_CHUNKS);
+    else
+        hipLaunchKernelGGL(film_bwd_kernel, dim3(FILM_CHUNKS, B), dim3(256), 2 * 256 * sizeof(float), st, du, x, gamma, beta, dx, ws, B, HW, C, alpha, FILM_CHUNKS);
+    hipLaunchKernelGGL(film_bwd_final_kernel, dim3((B * C + 15) / 16), dim3(256), 0, st, (const float*)ws, dgamma, dbeta, B, C, FILM_CHUNKS);
     return MMSEG_CHECK_LAUNCH();
 }
 
