@@ -69,6 +69,8 @@ def kernel_name(kid, prec):
         return '%s<%d, %d, %d, %d, %s>' % (_FAMILY[fam], bm, bn, wm, wn, tf)
     if fam == 6:
         return '%s<%d, %d, %d, %d, %d, %s>' % (_FAMILY[fam], bm, bn, wm, wn, prec, tf)
+    if fam == 14:
+        return 'conv_wgrad_tr_anyw_kernel<%d, %d, %d, %d, %d>' % (bm, bn, wm, wn, prec)
     if fam == 3:
         return 'conv_direct_kernel<8, 8, 3>'
     if fam == 5:

@@ -82,6 +82,8 @@ int mmseg_conv2d_wprep(const float* w, float* out, int KH, int KW, int Cin, int 
  * strided store -- no multiplications by the zeros of a dilated gradient.  wt from mmseg_conv2d_wprep_parity. */
 int mmseg_conv2d_parity_taps(int K, int stride, int p);
 int mmseg_conv2d_wprep_parity(const float* w, float* out, int KH, int KW, int Cin, int Cout, int stride, int ph, int pw, void* stream);
+/* all stride x stride classes in one launch: out = the class images back to back in (ph, pw) raster order (what mmseg_conv2d_dgrad_parity_all reads) */
+int mmseg_conv2d_wprep_parity_all(const float* w, float* out, int KH, int KW, int Cin, int Cout, int stride, void* stream);
 int mmseg_conv2d_dgrad_parity(const float* dy, const float* wt, float* dx, int B, int Ho, int Wo, int Cout, int H, int W, int Cin,
                               int TH, int TW, int stride, int ph, int pw, void* stream);
 /* data gradient of the discriminators' first layer (models/discriminator.py:24: 4x4, stride 2, valid; Cin = 1 or 4, Cout = 64):

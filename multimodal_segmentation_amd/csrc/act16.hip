@@ -52,29 +52,15 @@ __global__ __launch_bounds__(256) void bn16_partial_kernel(const void* __restric
     }
 }
 
-__device__ __forceinline__ void reduce_partials16(const float* __restrict__ part, int nblk, int C, int c, int lane, float& s1, float& s2,
-                                                  float* sm /* 512 floats */) {
-    float a1 = 0.f, a2 = 0.f;
-    if (c < C) {
-#pragma unroll 4
-        for (int b = lane; b < nblk; b += 4) { a1 += part[((size_t)b * 2) * C + c]; a2 += part[((size_t)b * 2 + 1) * C + c]; }
-    }
-    sm[threadIdx.x] = a1; sm[256 + threadIdx.x] = a2;
-    __syncthreads();
-    const int cl = threadIdx.x & 63;
-    s1 = sm[cl] + sm[64 + cl] + sm[128 + cl] + sm[192 + cl];
-    s2 = sm[256 + cl] + sm[320 + cl] + sm[384 + cl] + sm[448 + cl];
-}
-
 template <int HX>
-__global__ void bn16_stats_final_kernel(const float* __restrict__ part, const void* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(FIN_NT) void bn16_stats_final_kernel(const float* __restrict__ part, const void* __restrict__ x, const float* __restrict__ gamma,
                                         const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,
                                         float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mov_mean,
                                         float* __restrict__ mov_var, int nblk, int C, long M, float eps, float momentum) {
-    __shared__ float sm[512];
+    __shared__ float sm[2 * FIN_NT];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     float s1, s2;
-    reduce_partials16(part, nblk, C, c, lane, s1, s2, sm);
+    reduce_partials_64(part, nblk, C, c, lane, s1, s2, sm);
     if (c >= C || lane != 0) return;
     const float invM = 1.f / (float)M;
     const float d = s1 * invM;
@@ -108,13 +94,13 @@ __global__ void bn16_apply_kernel(const void* __restrict__ x, const float* __res
     }
 }
 
-__global__ void bn16_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ mean,
+__global__ __launch_bounds__(FIN_NT) void bn16_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ mean,
                                       const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                       float* __restrict__ coef /* [3][C] */, int nblk, int C, long M, int accumulate) {
-    __shared__ float sm[512];
+    __shared__ float sm[2 * FIN_NT];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     float s1, s2;
-    reduce_partials16(part, nblk, C, c, lane, s1, s2, sm);
+    reduce_partials_64(part, nblk, C, c, lane, s1, s2, sm);
     if (c >= C || lane != 0) return;
     if (dgamma) {
         if (accumulate) { dbeta[c] += s1; dgamma[c] += s2; }
@@ -360,7 +346,7 @@ int mmseg_bn_stats_t(const void* x, const float* gamma, const float* beta, float
     const long rpb = (M + nblk - 1) / nblk;
 #define L(HX) hipLaunchKernelGGL((bn16_partial_kernel<0, HX, 0>), dim3(nblk, C / 64), dim3(256), 0, st, x, (const void*)nullptr, (const void*)nullptr, \
                                  (const float*)nullptr, (const float*)nullptr, ws, M, C, rpb, 0);                                                       \
-              hipLaunchKernelGGL((bn16_stats_final_kernel<HX>), dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, x, gamma, beta, mean, invstd, \
+              hipLaunchKernelGGL((bn16_stats_final_kernel<HX>), dim3((C + 63) / 64), dim3(FIN_NT), 0, st, (const float*)ws, x, gamma, beta, mean, invstd, \
                                  scale, shift, mov_mean, mov_var, nblk, C, M, eps, momentum)
     DISPATCH_H(hx, L);
 #undef L
@@ -383,7 +369,7 @@ int mmseg_bn_bwd_t(const void* dy, const void* y, const void* x, const float* ga
     const long rpb = (M + nblk - 1) / nblk;
     const long n4 = M * (C / 4);
 #define L(HX, HY) hipLaunchKernelGGL((bn16_partial_kernel<1, HX, HY>), dim3(nblk, C / 64), dim3(256), 0, st, x, dy, y, mean, invstd, ws, M, C, rpb, relu); \
-                  hipLaunchKernelGGL(bn16_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta,   \
+                  hipLaunchKernelGGL(bn16_bwd_final_kernel, dim3((C + 63) / 64), dim3(FIN_NT), 0, st, (const float*)ws, gamma, mean, invstd, dgamma, dbeta,   \
                                      coef, nblk, C, M, accumulate);                                                                                      \
                   hipLaunchKernelGGL((bn16_bwd_apply_kernel<HX, HY>), dim3(grid16(n4)), dim3(256), 0, st, dy, y, x, (const float*)coef, dx, n4, C / 4, relu)
     DISPATCH_HH(hx, hy, L);

@@ -1582,8 +1582,10 @@ __device__ __forceinline__ void lp_pair(int pair, int& cq, int& pg) {
     pg = (rest / G) * PGL + pair % PGL;
 }
 
-template <int BKT, int BNT, int WM, int WN, int PREC = 0, bool TWO = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams q) {
+// ANYW: any output width >= 4 and stride 1 or 2 (the discriminators' 4x4 layers: Wo = 62, 30, 27): the 4 pixels of a thread's block may
+// straddle a row (and sample) boundary, so each pixel carries its own (sample, row, column) -- 3 more VALU per 16-byte load.
+template <int BKT, int BNT, int WM, int WN, int PREC, bool TWO, bool ANYW>
+__device__ __forceinline__ void conv_wgrad_tr_body(const WgradParams& q) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BKT / WM / 32, TN = BNT / WN / 32;
     constexpr int PT = 32;                               // pixels per LDS stage = K depth of one tile pair
@@ -1706,9 +1708,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
             const int rowoff = a_b[it] * a_sb[it] + (hi >> a_sh[it]) * a_sr[it] + a_c[it];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int wi = wi0 + j * p.stride;
-                const bool ok = rowok && (unsigned)wi < (unsigned)p.W;
-                const int off = rowoff + (wi >> a_sh[it]) * a_sp[it];
+                int wi = wi0 + j * p.stride, roff = rowoff;
+                bool rok = rowok;
+                if constexpr (ANYW) {
+                    int wo = a_wo[it] + j, ho = a_ho[it], b = a_b[it];
+                    if (wo >= p.Wo) { wo -= p.Wo; ++ho; if (ho >= p.Ho) { ho -= p.Ho; ++b; } }
+                    const int hj = ho * p.stride + a_dh[it];
+                    wi = wo * p.stride + a_dw[it];
+                    rok = a_ok[it] && (unsigned)hj < (unsigned)p.H && ps + 4 * a_pg[it] + j < pend;
+                    roff = b * a_sb[it] + (hj >> a_sh[it]) * a_sr[it] + a_c[it];
+                }
+                const bool ok = rok && (unsigned)wi < (unsigned)p.W;
+                const int off = roff + (wi >> a_sh[it]) * a_sp[it];
                 // descriptors stay wave-uniform: with two inputs both loads are issued, the unselected one out of range (zero bits)
                 if constexpr (!TWO) ra[it][j] = ldraw(r1, off, ok, x16);
                 else ra[it][j] = ldraw(r1, off, ok && a_from1[it], x16) | ldraw(r2, off, ok && !a_from1[it], x16);
@@ -1885,6 +1896,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams
     }
 }
 
+template <int BKT, int BNT, int WM, int WN, int PREC = 0, bool TWO = false>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_kernel(WgradParams q) {
+    conv_wgrad_tr_body<BKT, BNT, WM, WN, PREC, TWO, false>(q);
+}
+template <int BKT, int BNT, int WM, int WN, int PREC = 0>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tr_anyw_kernel(WgradParams q) {
+    conv_wgrad_tr_body<BKT, BNT, WM, WN, PREC, false, true>(q);
+}
+
 template <int BKT, int BNT, int WM, int WN, bool TWO>
 static void launch_wgrad_tr_prec(const WgradParams& q, dim3 grid, dim3 block, hipStream_t st) {
     if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_wgrad_tr_kernel<BKT, BNT, WM, WN, 1, TWO>), grid, block, 0, st, q);
@@ -1898,6 +1918,17 @@ static int launch_wgrad_tr(const WgradParams& q, int S, hipStream_t st) {
     if (q.c.C2 > 0) g_last_kernel += 500000;            // the two-input instantiation
     if (q.c.C2 > 0) launch_wgrad_tr_prec<BKT, BNT, WM, WN, true>(q, grid, block, st);
     else launch_wgrad_tr_prec<BKT, BNT, WM, WN, false>(q, grid, block, st);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+// the any-width instances (one input tensor)
+template <int BKT, int BNT, int WM, int WN>
+static int launch_wgrad_tr_anyw(const WgradParams& q, int S, hipStream_t st) {
+    dim3 grid(((q.c.K + BKT - 1) / BKT) * ((q.c.Cout + BNT - 1) / BNT) * S), block(WM * WN * 64);
+    MMSEG_SET_LAST(14, BKT, BNT);
+    if (g_conv_bf16 == 1) hipLaunchKernelGGL((conv_wgrad_tr_anyw_kernel<BKT, BNT, WM, WN, 1>), grid, block, 0, st, q);
+    else if (g_conv_bf16 == 2) hipLaunchKernelGGL((conv_wgrad_tr_anyw_kernel<BKT, BNT, WM, WN, 2>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((conv_wgrad_tr_anyw_kernel<BKT, BNT, WM, WN, 0>), grid, block, 0, st, q);
     return MMSEG_CHECK_LAUNCH();
 }
 
@@ -1999,6 +2030,27 @@ __global__ void wprep_parity_kernel(const float* __restrict__ w, float* __restri
         const int th = r % TH; const int ci = r / TH;
         const int kh = ph + s * (TH - 1 - th), kw = pw + s * (TW - 1 - tw);
         wimg_store(out, i, w[(((long)kh * KW + kw) * Cin + ci) * Cout + co], prec);
+    }
+}
+
+// all s x s parity classes in one launch: grid.y = class (ph * s + pw); the classes' images lie back to back in raster order
+__global__ void wprep_parity_all_kernel(const float* __restrict__ w, float* __restrict__ out, int KH, int KW, int Cin, int Cout, int s, int prec) {
+    const int ph = blockIdx.y / s, pw = blockIdx.y % s;
+    long off = 0;
+    for (int c = 0; c < (int)blockIdx.y; ++c) {
+        const int qh = c / s, qw = c % s;
+        const int th = qh < KH ? (KH - qh + s - 1) / s : 0, tw = qw < KW ? (KW - qw + s - 1) / s : 0;
+        off += (long)th * tw * Cin * Cout;
+    }
+    const int TH = ph < KH ? (KH - ph + s - 1) / s : 0, TW = pw < KW ? (KW - pw + s - 1) / s : 0;
+    const long n = (long)TH * TW * Cin * Cout;
+    float* o = out + off;                     // class images start at fp32-element offsets in every precision (as mmseg_conv2d_dgrad_parity_all reads them)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int co = i % Cout; long r = i / Cout;
+        const int tw = r % TW; r /= TW;
+        const int th = r % TH; const int ci = r / TH;
+        const int kh = ph + s * (TH - 1 - th), kw = pw + s * (TW - 1 - tw);
+        wimg_store(o, i, w[(((long)kh * KW + kw) * Cin + ci) * Cout + co], prec);
     }
 }
 
@@ -2209,7 +2261,7 @@ long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int 
     const long S = wgrad_splits(M, K, Cout);
     long need = wgrad_ws_floats(S, K * Cout);   // slabs (+ first-level partial sums); one slab even for S = 1
                                                 // (accumulating launches stage their single slab)
-    if (wgrad_tr_enabled() && Wo % 4 == 0) {    // the transposed-staging kernel may take this geometry: its own split
+    if (wgrad_tr_enabled() && Wo >= 4) {        // the transposed-staging kernel may take this geometry: its own split
         const long need_tr = wgrad_ws_floats(wgrad_tr_splits(M, K, Cout, nullptr), K * Cout);
         if (need_tr > need) need = need_tr;
     }
@@ -2263,9 +2315,13 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
                       (long)B * H * W * C2 * esx < lim && (long)p.M * Cout * esd < lim;
     // transposed-staging kernel: 4 consecutive pixels of a thread's block lie in one output row
     const bool tr = fast && wgrad_tr_enabled() && stride == 1 && Wo % 4 == 0 && Ho > 32 / Wo && !(C1 == 8 && C2 == 0 && Cout == 8);
+    // ... or the any-width instance: each pixel with its own coordinates (the discriminators' 4x4 layers, stride 1 or 2, odd widths)
+    static const bool anyw_on = ab_int("MMSEG_WGRAD_TR_ANYW", 1) != 0;
+    const bool tr_any = anyw_on && !tr && fast && wgrad_tr_enabled() && io == 0 && (stride == 1 || stride == 2) && Wo >= 4 && Ho > 32 / Wo &&
+                        C2 == 0 && !ups && Cout > 32 && wgrad_tr_bkt(p.K, Cout) == 128;
     int chunk;
     int S;
-    if (tr) S = wgrad_tr_splits(p.M, p.K, Cout, &chunk);
+    if (tr || tr_any) S = wgrad_tr_splits(p.M, p.K, Cout, &chunk);
     else {
         S = wgrad_splits(p.M, p.K, Cout);
         chunk = (p.M + S - 1) / S;
@@ -2337,6 +2393,8 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
     else if (tr && Cout > 64) rc = launch_wgrad_tr<128, 128, 2, 2>(q, S, st);
     else if (tr && Cout > 32) rc = launch_wgrad_tr<128, 64, 2, 2>(q, S, st);
     else if (tr) rc = launch_wgrad_tr<128, 32, 4, 1>(q, S, st);
+    else if (tr_any && Cout > 64) rc = launch_wgrad_tr_anyw<128, 128, 2, 2>(q, S, st);
+    else if (tr_any) rc = launch_wgrad_tr_anyw<128, 64, 2, 2>(q, S, st);
     else if (fast && Cout > 64) rc = launch_wgrad_fast<128, 128, 2, 2>(q, S, st);
     else if (fast && Cout > 32) rc = launch_wgrad_fast<128, 64, 2, 2>(q, S, st);
     else if (fast) rc = launch_wgrad_fast<128, 32, 4, 1>(q, S, st);
@@ -2373,6 +2431,22 @@ int mmseg_conv2d_wprep_parity(const float* w, float* out, int KH, int KW, int Ci
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wprep_parity_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH, KW, Cin, Cout, TH, TW, stride, ph, pw, g_conv_bf16);
+    return MMSEG_CHECK_LAUNCH();
+}
+// every parity class of a stride-s kernel in one launch: out = the classes' images back to back in (ph, pw) raster order
+int mmseg_conv2d_wprep_parity_all(const float* w, float* out, int KH, int KW, int Cin, int Cout, int stride, void* stream) {
+    if (stride < 1 || stride > 8) return (int)hipErrorInvalidValue;
+    long nmax = 0;
+    for (int ph = 0; ph < stride; ++ph)
+        for (int pw = 0; pw < stride; ++pw) {
+            const long n = (long)mmseg_conv2d_parity_taps(KH, stride, ph) * mmseg_conv2d_parity_taps(KW, stride, pw) * Cin * Cout;
+            if (n > nmax) nmax = n;
+        }
+    if (nmax == 0) return 0;
+    long blocks = (nmax + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wprep_parity_all_kernel, dim3((unsigned)blocks, stride * stride), dim3(256), 0, (hipStream_t)stream, w, out, KH, KW, Cin, Cout,
+                       stride, g_conv_bf16);
     return MMSEG_CHECK_LAUNCH();
 }
 int mmseg_conv2d_wflip(const float* w, float* wt, int KH, int KW, int Cin, int Cout, void* stream) {

@@ -122,24 +122,7 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
     }
 }
 
-// sum the per-block partials of 64 channels with FIN_LPC lanes per channel (blockDim FIN_NT); result valid where lane == 0.  (Four
-// lanes per channel walked up to 128 partials each with dependent loads: ~10.7 us per launch, 104 launches per training iteration.)
-constexpr int FIN_LPC = 16, FIN_NT = 64 * FIN_LPC;
-__device__ __forceinline__ void reduce_partials_64(const float* __restrict__ part, int nblk, int C, int c, int lane,
-                                                   float& s1, float& s2, float* sm /* 2 * FIN_NT floats */) {
-    float a1 = 0.f, a2 = 0.f;
-    if (c < C) {
-#pragma unroll 8
-        for (int b = lane; b < nblk; b += FIN_LPC) { a1 += part[((size_t)b * 2) * C + c]; a2 += part[((size_t)b * 2 + 1) * C + c]; }
-    }
-    sm[threadIdx.x] = a1; sm[FIN_NT + threadIdx.x] = a2;
-    __syncthreads();
-    const int cl = threadIdx.x & 63;
-    s1 = 0.f; s2 = 0.f;
-#pragma unroll
-    for (int l = 0; l < FIN_LPC; ++l) { s1 += sm[l * 64 + cl]; s2 += sm[FIN_NT + l * 64 + cl]; }     // fixed order
-}
-
+// (reduce_partials_64 / FIN_NT: common.hpp -- shared with the typed-I/O kernels of act16.hip, which must sum in the same order)
 // training statistics -> mean, invstd, fused scale/shift, moving-average update.  grid = ceil(C/64), block FIN_NT
 __global__ __launch_bounds__(FIN_NT) void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,

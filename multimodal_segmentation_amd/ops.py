@@ -216,13 +216,7 @@ def _wprep_parity_all(w, KH, KW, Cin, Cout, stride, taps, wkey=None):
         out = _ws('wprep_parity_all', n, w.device)[:n]
     else:
         out = ent[1] if (ent is not None and ent[1].numel() == n) else torch.empty(n, dtype=torch.float32, device=w.device)
-    off = 0
-    for qh in range(stride):
-        for qw in range(stride):
-            sz = taps[0][qh] * taps[1][qw] * Cin * Cout
-            if sz:
-                N.call('mmseg_conv2d_wprep_parity', w, out[off:off + sz], KH, KW, Cin, Cout, stride, qh, qw)
-            off += sz
+    N.call('mmseg_conv2d_wprep_parity_all', w, out, KH, KW, Cin, Cout, stride)
     if wkey is not None:
         _wprep_cache[key] = (_wver(wkey), out)
     return out

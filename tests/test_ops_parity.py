@@ -124,6 +124,10 @@ CONV_CASES = [
     (2, 37, 41, 1, 0, 64, 4, 2, 'valid', 'leaky', False),      # D_Image first layer: smallk<4, 1>
     (2, 19, 23, 1, 0, 16, 3, 1, 'same', None, False),          # 4 lanes per pixel
     (1, 70, 70, 64, 0, 5, 1, 1, 'same', None, False),          # more pixels than one pass of the grid
+    # the discriminators' 4x4 layers at odd output widths: weight gradient on the any-width transposed-staging kernel (pixel quads that
+    # straddle row and sample boundaries, stride 2 and stride 1, a pixel count that is not a multiple of 4)
+    (3, 64, 60, 64, 0, 128, 4, 2, 'valid', 'leaky', False),    # Ho x Wo = 31 x 29
+    (3, 30, 30, 64, 0, 256, 4, 1, 'valid', 'leaky', False),    # 27 x 27: M = 2187
 ]
 
 
