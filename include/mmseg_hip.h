@@ -77,6 +77,9 @@ int mmseg_conv2d_last_kernel(void);
  * fp32-sized buffer) -- prepare it in the mode the convolution runs in. */
 int mmseg_conv2d_fast_path(int C1, int C2, int Cout, int transposed);
 int mmseg_conv2d_wprep(const float* w, float* out, int KH, int KW, int Cin, int Cout, int mode, void* stream);
+/* the mode 0 / 1 images of n weights in ONE launch (all images of a model after its optimiser step); table: device int64 [n + 1][8] rows
+ * {src, dst, KH*KW, Cin, Cout, mode, first block, 0}, row n carries the total block count; blocks per row = taps * ceil(Cin/32) * ceil(Cout/32) */
+int mmseg_conv2d_wprep_batch(const long long* table, int n, long total_blocks, void* stream);
 /* data gradient of a STRIDED convolution, one launch per parity class (ph, pw) of the input pixels: only the taps
  * kh = ph + s*a, kw = pw + s*b contribute, so each class is a stride-1 convolution over dy with a small sub-kernel and a
  * strided store -- no multiplications by the zeros of a dilated gradient.  wt from mmseg_conv2d_wprep_parity. */

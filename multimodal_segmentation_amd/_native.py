@@ -19,7 +19,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), 'include', 'mmseg_hip.h')
 SOURCES = ('conv.hip', 'pointwise.hip', 'norm.hip', 'act16.hip', 'dense.hip', 'tps.hip', 'augment.hip', 'loss.hip', 'pairloss.hip', 'optim.hip')
 
 _CTYPES = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'void*': ctypes.c_void_p,
-           'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p, 'const int*': ctypes.c_void_p, 'const void*': ctypes.c_void_p}
+           'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p, 'const int*': ctypes.c_void_p, 'const void*': ctypes.c_void_p,
+           'const long long*': ctypes.c_void_p}
 
 
 class NativeLibraryError(RuntimeError):
@@ -98,7 +99,7 @@ def _ptr(t, device, ctype='float*'):
         if t.dtype not in (torch.float32, torch.bfloat16, torch.float16) or not t.is_contiguous() or t.device != device:
             raise ValueError('kernel operand (%s) must be a contiguous fp32 / bf16 / fp16 tensor on %s (got %s %s)' % (ctype, device, t.dtype, t.device))
         return t.data_ptr()
-    want = torch.int32 if 'int' in ctype else torch.float32
+    want = torch.int64 if 'long long' in ctype else (torch.int32 if 'int' in ctype else torch.float32)
     if t.dtype != want or not t.is_contiguous() or t.device != device:
         raise ValueError('kernel operand (%s) must be a contiguous %s tensor on %s (got %s %s contiguous=%s)'
                          % (ctype, want, device, t.dtype, t.device, t.is_contiguous()))

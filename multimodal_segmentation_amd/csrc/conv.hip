@@ -2033,6 +2033,47 @@ __global__ void wprep_parity_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// Several weight images in ONE launch (all the forward / data-gradient images of one model after its optimiser step: ~80 launches of
+// 4-7 us per iteration otherwise).  table: n + 1 rows of 8 int64 {src, dst, ntaps, Cin, Cout, mode, first block, -}; a block finds its row
+// by bisection over the first-block column (row n holds the total), then handles one 32 x 32 (ci, co) tile of one tap:
+//   mode 0: out[co][tap][ci] = w[tap][ci][co]  (transpose through LDS, as wprep_fwd_tiled_kernel)
+//   mode 1: out[ci][tap][co] = w[ntaps-1-tap][ci][co]  (row copy)
+__global__ __launch_bounds__(256) void wprep_batch_kernel(const long long* __restrict__ table, int n, int prec) {
+    __shared__ float t[32][33];
+    const long long b = blockIdx.x;
+    int lo = 0, hi = n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (table[(size_t)mid * 8 + 6] <= b) lo = mid; else hi = mid; }
+    const long long* r = table + (size_t)lo * 8;
+    const float* w = reinterpret_cast<const float*>(r[0]);
+    float* out = reinterpret_cast<float*>(r[1]);
+    const int ntaps = (int)r[2], Cin = (int)r[3], Cout = (int)r[4], mode = (int)r[5];
+    int l = (int)(b - r[6]);
+    const int ntx = (Cout + 31) / 32, nty = (Cin + 31) / 32;
+    const int co0 = (l % ntx) * 32; l /= ntx;
+    const int ci0 = (l % nty) * 32, tap = l / nty;
+    if (tap >= ntaps) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (mode == 0) {
+        const float* src = w + (size_t)tap * Cin * Cout;
+        for (int rr = ty; rr < 32; rr += 8) {
+            const int ci = ci0 + rr, co = co0 + tx;
+            t[rr][tx] = (ci < Cin && co < Cout) ? src[(size_t)ci * Cout + co] : 0.f;
+        }
+        __syncthreads();
+        const size_t K = (size_t)ntaps * Cin;
+        for (int rr = ty; rr < 32; rr += 8) {
+            const int co = co0 + rr, ci = ci0 + tx;
+            if (co < Cout && ci < Cin) wimg_store(out, (size_t)co * K + (size_t)tap * Cin + ci, t[tx][rr], prec);
+        }
+    } else {
+        const float* src = w + (size_t)(ntaps - 1 - tap) * Cin * Cout;
+        for (int rr = ty; rr < 32; rr += 8) {
+            const int ci = ci0 + rr, co = co0 + tx;
+            if (ci < Cin && co < Cout) wimg_store(out, ((size_t)ci * ntaps + tap) * Cout + co, src[(size_t)ci * Cout + co], prec);
+        }
+    }
+}
+
 // all s x s parity classes in one launch: grid.y = class (ph * s + pw); the classes' images lie back to back in raster order
 __global__ void wprep_parity_all_kernel(const float* __restrict__ w, float* __restrict__ out, int KH, int KW, int Cin, int Cout, int s, int prec) {
     const int ph = blockIdx.y / s, pw = blockIdx.y % s;
@@ -2431,6 +2472,13 @@ int mmseg_conv2d_wprep_parity(const float* w, float* out, int KH, int KW, int Ci
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wprep_parity_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, out, KH, KW, Cin, Cout, TH, TW, stride, ph, pw, g_conv_bf16);
+    return MMSEG_CHECK_LAUNCH();
+}
+// the images of `n` weights in one launch; table: device int64 [n + 1][8] rows {src, dst, KH*KW, Cin, Cout, mode (0 | 1), first block, 0},
+// row n = {.., total blocks, ..}; blocks of a row = taps * ceil(Cin / 32) * ceil(Cout / 32).  The caller keeps src / dst alive.
+int mmseg_conv2d_wprep_batch(const long long* table, int n, long total_blocks, void* stream) {
+    if (n < 1 || total_blocks < 1 || total_blocks >= (1L << 31)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(wprep_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, n, g_conv_bf16);
     return MMSEG_CHECK_LAUNCH();
 }
 // every parity class of a stride-s kernel in one launch: out = the classes' images back to back in (ph, pw) raster order

@@ -146,6 +146,43 @@ _bnfold_cache = {}
 _owner_version = {}          # id(nn.Model) -> version of that model's weights (bumped by its optimiser steps only)
 
 
+_wprep_batch = {}            # id(nn.Model) -> {'ents': {cache key: (src ptr, image, taps, Cin, Cout, mode, wkey)}, 'table': tensor | None, 'blocks': int}
+_wprep_batch_on = [True]     # False: every image is re-laid out lazily by its own launch again (tests compare the two)
+
+
+def _wprep_register(key, wkey, w, out, ntaps, Cin, Cout, mode):
+    """remember a cached mode 0 / 1 image of a model's parameter: the model's next optimiser step refreshes all of them in ONE launch"""
+    if not (isinstance(wkey, tuple) and len(wkey) == 2 and isinstance(wkey[0], int) and mode in (0, 1) and w.is_cuda):
+        return
+    b = _wprep_batch.setdefault(wkey[1], {'ents': {}, 'table': None, 'blocks': 0})
+    ent = b['ents'].get(key)
+    if ent is None or ent[0] != w.data_ptr() or ent[1] is not out:
+        b['ents'][key] = (w.data_ptr(), out, ntaps, Cin, Cout, mode, wkey)
+        b['table'] = None
+
+
+def _wprep_refresh(owner):
+    """all registered images of `owner`'s parameters in one launch (mmseg_conv2d_wprep_batch), stamped with the current version"""
+    b = _wprep_batch.get(owner)
+    if not b or not b['ents'] or not _wprep_batch_on[0]:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    ents = list(b['ents'].items())
+    dev = ents[0][1][1].device
+    if b['table'] is None:
+        rows, blk = [], 0
+        for _, (src, out, ntaps, Cin, Cout, mode, _wk) in ents:
+            rows.append([src, out.data_ptr(), ntaps, Cin, Cout, mode, blk, 0])
+            blk += ntaps * ((Cin + 31) // 32) * ((Cout + 31) // 32)
+        rows.append([0, 0, 0, 0, 0, 0, blk, 0])
+        b['table'] = torch.tensor(rows, dtype=torch.int64).to(dev)
+        b['blocks'] = blk
+    N.call('mmseg_conv2d_wprep_batch', b['table'], len(ents), b['blocks'])
+    for key, ent in ents:
+        _wprep_cache[key] = (_wver(ent[6]), ent[1])
+
+
 def bump_weight_version(owner=None):
     """Invalidate the cached weight re-layouts (called whenever weights change: optimiser step, set_weights).  `owner` = id of the
     nn.Model whose arena changed: only the images of ITS parameters become stale -- a discriminator's Adam step no longer makes the
@@ -154,8 +191,10 @@ def bump_weight_version(owner=None):
     graph capture, broadcast)."""
     if owner is None:
         _weight_version[0] += 1
+        _wprep_batch.clear()         # arenas may have moved (set_weights, broadcast): the images re-register as they are re-laid out
     else:
         _owner_version[owner] = _owner_version.get(owner, 0) + 1
+        _wprep_refresh(owner)
     _bn_state_version[0] += 1
 
 
@@ -181,6 +220,7 @@ def _wprep(w, KH, KW, Cin, Cout, mode, wkey=None):
     out = ent[1] if (ent is not None and ent[1].numel() == w.numel()) else torch.empty(w.numel(), dtype=torch.float32, device=w.device)
     N.call('mmseg_conv2d_wprep', w, out, KH, KW, Cin, Cout, mode)
     _wprep_cache[key] = (_wver(wkey), out)
+    _wprep_register(key, wkey, w, out, KH * KW, Cin, Cout, mode)
     return out
 
 

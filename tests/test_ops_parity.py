@@ -510,3 +510,71 @@ def test_spectral_reg_multi(n, device):
     P.spectral_reg_grad_accumulate(ws_, sgn, grads)
     for g, gr in zip(grads, grefs):
         _close(g - 0.5, gr, 'grad', 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_weight_images_of_a_model_in_one_launch(mode):
+    """mmseg_conv2d_wprep_batch (the forward / data-gradient images of all of a model's kernels after its optimiser step) == one
+    mmseg_conv2d_wprep launch per image, bit for bit; odd channel counts and tap counts, both layouts, both element types"""
+    from multimodal_segmentation_amd import _native as N
+    dev = torch.device('cuda')
+    shapes = [(3, 3, 64, 64, 0), (3, 3, 64, 64, 1), (4, 4, 128, 256, 0), (1, 1, 40, 36, 1), (5, 5, 20, 20, 0), (3, 3, 96, 8, 1), (2, 3, 33, 65, 0)]
+    prev = P.set_conv_precision(mode)
+    try:
+        ws_, refs, outs, rows, blk = [], [], [], [], 0
+        for i, (KH, KW, Cin, Cout, m) in enumerate(shapes):
+            w = rnd(KH, KW, Cin, Cout, seed=70 + i).to(dev)
+            ref, out = torch.zeros(w.numel(), device=dev), torch.zeros(w.numel(), device=dev)
+            N.call('mmseg_conv2d_wprep', w, ref, KH, KW, Cin, Cout, m)
+            rows.append([w.data_ptr(), out.data_ptr(), KH * KW, Cin, Cout, m, blk, 0])
+            blk += KH * KW * ((Cin + 31) // 32) * ((Cout + 31) // 32)
+            ws_.append(w); refs.append(ref); outs.append(out)
+        rows.append([0, 0, 0, 0, 0, 0, blk, 0])
+        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        N.call('mmseg_conv2d_wprep_batch', table, len(shapes), blk)
+        torch.cuda.synchronize()
+        for shp, ref, out in zip(shapes, refs, outs):
+            assert torch.equal(ref, out), shp
+    finally:
+        P.set_conv_precision(prev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('multi_stream', [False, True])
+def test_training_iterations_with_batched_weight_images_are_bitwise_the_lazy_ones(multi_stream):
+    """three DAFNet iterations with the per-model image refresh after each optimiser step == the same iterations with every image
+    re-laid out by its own launch on first use (ops._wprep_batch_on off), bit for bit in every weight arena"""
+    from tests import helpers as Hh
+    from multimodal_segmentation_amd import nn
+    from multimodal_segmentation_amd.configuration import dafnet_config_chaos
+    from multimodal_segmentation_amd.models.dafnet import DAFNet
+    from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
+
+    def run(batched):
+        P._wprep_batch_on[0] = batched
+        P.bump_weight_version()
+        nn.set_default_device('cuda:0')
+        np.random.seed(77)
+        conf = Hh.make_conf(dafnet_config_chaos, 64, batch_size=4, multi_stream=multi_stream)
+        model = DAFNet(conf)
+        model.build()
+        model.Enc_Modality._eps_rng = None
+        ex = DAFNetExecutor(conf, model)
+        np.random.seed(78)
+        ex.init_train_data(slices_per_volume=3)
+        losses = {n: [] for n in ex.get_loss_names()}
+        for _ in range(3):
+            ex.train_batch(losses)
+        torch.cuda.synchronize()
+        registered = sum(len(b['ents']) for b in P._wprep_batch.values())
+        ms = model._generator_models() + [model.D_Mask, model.D_Image1, model.D_Image2]
+        return [m.arena.detach().clone() for m in ms], registered
+
+    try:
+        a, na = run(True)
+        b, _ = run(False)
+    finally:
+        P._wprep_batch_on[0] = True
+    assert na > 20                                   # the images were registered (and refreshed in batches)
+    assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
