@@ -39,6 +39,14 @@ def main():
                 continue
             d = json.loads(txt[-1])
             d['_label'] = label
+            # bench.py read gpu_busy_frac / traffic from the PREVIOUS session's files under profiles/ (this session's trace and PMC passes
+            # ran after it): restate them from this session's summaries so that the line and the files committed beside it agree
+            busy = os.path.join(EV, 'gpu_busy.txt')
+            if 'gpu_busy_frac' in d and os.path.exists(busy):
+                import re
+                m = re.search(r'= ([0-9.]+) % GPU-busy', open(busy).read())
+                if m:
+                    d['gpu_busy_frac']['value'] = float(m.group(1)) / 100.0
             out.write(json.dumps(d) + '\n')
             print('%-36s %8.2f slices/s  %8.2f ms' % (name, d['value'], d['ms_per_step']))
     for src, dst in (('final_kernel_stats.txt', 'r03_final_kernel_stats_bench_dafnet_film_256_bs8.txt'),
