@@ -44,7 +44,7 @@ _FAMILY = {1: 'conv_fast_kernel', 2: 'conv_fwd_kernel', 3: 'conv_direct_kernel',
            5: 'conv_dgrad_s2k4_smallc_kernel', 6: 'conv_wgrad_tr_kernel', 7: 'conv_wgrad_fast_kernel', 8: 'conv_wgrad_kernel',
            9: 'conv_wgrad_c8_kernel', 10: 'pw_reduce_kernel', 11: 'smallk_conv_kernel', 12: 'pw_reduce_wgrad_kernel',
            13: 'smallk_wgrad_kernel'}
-HBM_BOUND_FAMILIES = ('pw_reduce_kernel', 'smallk_conv_kernel', 'pw_reduce_wgrad_kernel', 'smallk_wgrad_kernel', 'conv_direct_kernel',
+HBM_BOUND_FAMILIES = ('pw_reduce_kernel', 'smallk_conv_kernel', 'pw_reduce_wgrad_kernel', 'smallk_wgrad_kernel', 'conv_direct_kernel', 'conv_direct_mfma_kernel',
                       'conv_wgrad_c8_kernel', 'conv_dgrad_s2k4_smallc_kernel')
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
 
@@ -72,7 +72,7 @@ def kernel_name(kid, prec):
     if fam == 14:
         return 'conv_wgrad_tr_anyw_kernel<%d, %d, %d, %d, %d>' % (bm, bn, wm, wn, prec)
     if fam == 3:
-        return 'conv_direct_kernel<8, 8, 3>'
+        return 'conv_direct_mfma_kernel<3>'
     if fam == 5:
         return 'conv_dgrad_s2k4_smallc_kernel<%d>' % bm
     if fam in (10, 12):             # <lanes per pixel, outputs, 16-byte vectors per lane>

@@ -936,6 +936,71 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
     }
 }
 
+// The same layer on the 4 x 4 x 1 MFMA (16 independent 4 x 4 outer products per instruction).  A lane still owns one output pixel and
+// requests its 9 taps up front (18 16-byte loads in flight); per (tap, input channel) it feeds the pixel's value as the A operand of two
+// MFMAs whose B operands are the weights of output channels (lane & 3) and 4 + (lane & 3) -- a block of the instruction is 4 consecutive
+// pixels x 4 channels, the accumulators hold (row = pixel of the quad, lane = channel).  Weights sit in LDS as [k][channel & 3][channel >> 2]:
+// one 8-byte broadcast read serves both MFMAs.  Same products in the same order per output as the VALU kernel above, no VALU arithmetic
+// left in the loop.  Blocks are renumbered so that consecutive image rows run on ONE XCD: the halo rows of a block are L2 hits instead
+// of a second and third fetch through the fabric -- PMC (`tools/pmc_direct_ab.sh`, batch 48): 294 -> 98 MB of reads per launch (1.0 x the
+// algorithmic bytes, was 3.0 x), 67.4 -> 61.8 us; the MFMA pipe is busy 40 % of the launch.  Measured and rejected: the
+// taps staged through LDS as one contiguous pixel range (79.9 us: 5 blocks per CU and a barrier between the load and MFMA phases), a
+// persistent block walking several tiles with the next tile's taps in flight (103.7 us: 2-3 waves per SIMD do not cover the latency).
+template <int KS>
+__global__ __launch_bounds__(256) void conv_direct_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int B, int H, int W, int pad, int act, float alpha) {
+    constexpr int CIN = 8, COUT = 8, NT = KS * KS;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) float wl[NT * CIN * COUT];
+    for (int i = threadIdx.x; i < NT * CIN * COUT; i += 256) {
+        const int k = i >> 3, co = i & 7;
+        wl[k * 8 + (co & 3) * 2 + (co >> 2)] = w[i];
+    }
+    __syncthreads();
+    const long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const long npix = (long)B * H * W;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(npix * CIN * 4), 0x00020000);
+    const bool live = idx < npix;
+    const int wq = idx % W; long r = idx / W;
+    const int hq = r % H; const int b = r / H;
+    const int j = threadIdx.x & 3;
+    const float b0 = bias ? bias[j] : 0.f, b1 = bias ? bias[4 + j] : 0.f;
+    f32x4 acc0 = {b0, b0, b0, b0}, acc1 = {b1, b1, b1, b1};
+    f32x4 xt[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int kh = t / KS, kw = t - kh * KS;
+        const int hi = hq + kh - pad, wi = wq + kw - pad;
+        const bool ok = live && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const int off = (((b * H + hi) * W + wi) * CIN) * 4;
+        xt[t][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : 0x7ffffff0, 0, 0));
+        xt[t][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off + 16 : 0x7ffffff0, 0, 0));
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float* wt = wl + t * CIN * COUT + j * 2;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            const f32x2 wv = *reinterpret_cast<const f32x2*>(wt + ci * 8);
+            const float xs = xt[t][ci >> 2][ci & 3];
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs, wv[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(xs, wv[1], acc1, 0, 0, 0);
+        }
+    }
+    // accumulator register q of lane (quad, j) = output channel j (acc0) / 4 + j (acc1) of the quad's pixel q: transposed inside the quad
+    // a lane holds channels 0..3 / 4..7 of ITS pixel -- two 16-byte stores
+    float a0[4], a1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a0[e] = act_apply(acc0[e], act, alpha); a1[e] = act_apply(acc1[e], act, alpha); }
+    quad_transpose4(a0, j);
+    quad_transpose4(a1, j);
+    if (!live) return;
+    f32x4* dst = reinterpret_cast<f32x4*>(y + idx * COUT);
+    dst[0] = f32x4{a0[0], a0[1], a0[2], a0[3]};
+    dst[1] = f32x4{a1[0], a1[1], a1[2], a1[3]};
+}
+
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 #include "smallconv.hpp"
@@ -1009,8 +1074,13 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (p.C1 == 8 && p.C2 == 0 && p.Cout == 8 && p.KH == 3 && p.KW == 3 && p.stride == 1 && !p.transposed && !p.ups &&
         p.Ho == p.H && p.Wo == p.W && p.pad_h == 1 && p.pad_w == 1 && p.y2 == nullptr && p.w != nullptr && p.osh == 1 &&
         p.oscale == nullptr && aligned16(p.x1) && aligned16(p.y) && (long)p.M * 8 * 4 < (1L << 31) - 64 && p.io == 0) {
-        hipLaunchKernelGGL((conv_direct_kernel<8, 8, 3>), dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st,
-                           p.x1, p.w, p.bias, p.y, p.B, p.H, p.W, 1, p.act, p.alpha);
+        static const int direct_mfma = ab_int("MMSEG_DIRECT_MFMA", 1);       // 0 (measurement builds): the VALU kernel
+        if (direct_mfma)
+            hipLaunchKernelGGL((conv_direct_mfma_kernel<3>), dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st,
+                               p.x1, p.w, p.bias, p.y, p.B, p.H, p.W, 1, p.act, p.alpha);
+        else
+            hipLaunchKernelGGL((conv_direct_kernel<8, 8, 3>), dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st,
+                               p.x1, p.w, p.bias, p.y, p.B, p.H, p.W, 1, p.act, p.alpha);
         MMSEG_SET_LAST(3, 8, 8);
         return MMSEG_CHECK_LAUNCH();
     }

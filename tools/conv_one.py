@@ -6,7 +6,7 @@ import torch
 from multimodal_segmentation_amd import _native as N
 H, Cin, Cout = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 mode = sys.argv[4] if len(sys.argv) > 4 else 'fwd'
-B, k, p = 8, 3, 1
+B, k, p = int(os.environ.get("BATCH", "8")), 3, 1
 dev = torch.device('cuda')
 N.load()
 x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(k, k, Cin, Cout, device=dev) * 0.05
