@@ -96,6 +96,7 @@ class ConvTimer(object):
         self.seen = 0
         self.counts = {}      # kind -> total launches in the timed region (sampled or not)
         self.kcounts = {}     # rocprof kernel name -> total launches in the timed region
+        self.kwork = {}       # rocprof kernel name -> [flops, bytes] over ALL its launches while enabled (sampled or not)
         self.prec = 0
 
     def install(self):
@@ -160,6 +161,9 @@ class ConvTimer(object):
                 rc = timer._orig(full_name, *args)
                 kname = kernel_name(timer._orig('mmseg_conv2d_last_kernel'), timer.prec)     # which template instance ran
                 timer.kcounts[kname] = timer.kcounts.get(kname, 0) + 1
+                kw = timer.kwork.setdefault(kname, [0.0, 0.0])
+                kw[0] += flops
+                kw[1] += nbytes
                 if sampled:
                     e.record()
                     timer.records.append((kind, flops, nbytes, s, e, shape, kname))
@@ -371,7 +375,9 @@ def main():
         DTYPE_NAME[args.dtype] += ', discriminator phases on concurrent streams'
     if args.graphs:
         cfg['hip_graphs'] = True
-        args.no_conv_timer = True        # replayed launches do not pass through the Python call the timer hooks
+        # replayed launches do not pass through the Python call the timer hooks: the hooks only COUNT the launches and their algorithmic
+        # work during the first (eager) warm-up iteration; the durations come from the committed rocprofv3 trace of this command
+        args.conv_timer_stride = 1 << 30
         DTYPE_NAME[args.dtype] += ', trainer steps replayed from hipGraphs'
     cfg['folder'] = '/tmp/mmseg_bench'
     conf = EasyDict(cfg)
@@ -412,11 +418,13 @@ def main():
 
     _progress('warmup')
     losses = {n: [] for n in ex.get_loss_names()}
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        timer.enabled = bool(args.graphs) and i == 0          # --graphs: count one eager iteration's launches (see above)
         ex.train_batch(losses)
     sync()
+    graph_counts = (dict(timer.kcounts), {k: list(v) for k, v in timer.kwork.items()}) if args.graphs else None
     _progress('timed region')
-    timer.enabled = True
+    timer.enabled = not args.graphs
     dp.counters(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -557,6 +565,31 @@ def main():
                 fam[kind]['traffic'] = traffic.get('families', {}).get('conv_fwd' if kind == 'conv_fwd_kernel' else 'conv_wgrad', {}).get('hbm_bytes_per_launch')
         if fam:
             line['roofline_family'] = fam
+        if args.graphs and graph_counts and graph_counts[0]:
+            # --graphs: no per-launch events inside a replayed graph.  Per kernel instance: the algorithmic work of its launches in one
+            # (eager, counted) iteration / the average duration of that instance in the committed rocprofv3 kernel trace of THIS command
+            gname = 'r03_graphs_kernel_stats_bench_%s_%s_%d_bs%d_%s.txt' % (args.model, args.decoder, H, args.batch, args.dtype + ('_act16' if args.act16 else ''))
+            gpath = os.path.join(ROOT, 'profiles', gname)
+            if os.path.exists(gpath):
+                import re
+                avg_us = {}
+                for ln in open(gpath):
+                    m = re.match(r'(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$', ln)
+                    if m:
+                        avg_us[m.group(1).strip()] = float(m.group(4))
+                ents = []
+                for kname, n in graph_counts[0].items():
+                    if kname in avg_us and n > 0:
+                        fl, by = graph_counts[1][kname]
+                        k = {'flops': fl, 'bytes': by, 'ms': avg_us[kname] * 1e-3 * n, 'launches': n}
+                        ent = entry(k, n * args.steps, kname)
+                        ent['traffic'] = traffic.get('kernels', {}).get(kname, {}).get('hbm_bytes_per_launch')
+                        ents.append(ent)
+                ents.sort(key=lambda e: -e['gpu_ms_per_step'])
+                if ents:
+                    line['roofline'] = dict(ents[0], precision=prec_note, sampling='launches and algorithmic work counted in one eager iteration; '
+                                            'average launch duration from profiles/%s (rocprofv3 --kernel-trace of this command: replayed graphs)' % gname)
+                    line['roofline_kernels'] = [e for e in ents if e['gpu_ms_per_step'] >= 0.5 or e['bound'] == 'hbm']
         if multi is not None:
             line['multi_stream'] = multi
         # share of the timed window with a kernel running, from the rocprofv3 kernel trace of THIS command committed under profiles/
