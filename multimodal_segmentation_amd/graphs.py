@@ -36,10 +36,11 @@ def host_draw(fn, device):
     """A float32 array the step draws on the host (fn() -> numpy array) as a device tensor.  Eager: upload of fn().  While a step is
     being recorded: the next static buffer (already holding this step's draw); the replay refills the buffers in call order."""
     st = _recording
+    from . import nn
     if st is None:
-        return torch.from_numpy(np.ascontiguousarray(fn(), np.float32)).to(device)
+        return nn.host_to_device(fn(), device)       # asynchronous (a pageable `.to(device)` stalls the host until the GPU has drained)
     if st.mode == 'discover':
-        v = torch.from_numpy(np.ascontiguousarray(fn(), np.float32)).to(device)
+        v = nn.host_to_device(fn(), device)
         st.draws.append(_Draw(fn, torch.empty_like(v)))
         return v
     d = st.draws[st.draw_i]
