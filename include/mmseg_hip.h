@@ -257,9 +257,6 @@ int mmseg_tps_warp_bwd(const float* vol, const float* loc, const float* Mb, cons
 
 /* ---- batch gather + affine (rotation) augmentation (csrc/augment.hip): keras ImageDataGenerator(rotation_range=20)
  *      .flow of model_executors/base_executor.py:37-78,103-110 = scipy affine_transform(order=1, mode='nearest') ---- */
-/* small host -> device upload as a kernel on the caller's stream: src_host = device-accessible pinned host memory (nwords 4-byte words), kept
- * unchanged by the caller until the launch has run */
-int mmseg_upload_words(const void* src_host, void* dst, long nwords, void* stream);
 int mmseg_affine_gather(const float* data, const int* rows, const float* mat, float* out, int B, int H, int W, int C, int order,
                         void* stream);
 

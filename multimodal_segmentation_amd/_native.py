@@ -106,16 +106,6 @@ def _ptr(t, device, ctype='float*'):
     return t.data_ptr()
 
 
-def launch_raw(name, device, *args):
-    """`name` with raw (integer) pointer arguments on the current stream of `device` -- for operands that are not device tensors (the pinned
-    host source of mmseg_upload_words).  Raises on a non-zero hipError_t."""
-    lib = load()
-    rc = getattr(lib, name)(*(list(args) + [_stream_handle(device)]))
-    if rc != 0:
-        raise NativeLibraryError('%s failed with hipError_t %d' % (name, rc))
-    return rc
-
-
 def call(name, *args):
     """Launch `name` on the current stream of the operands' device.  Tensor arguments become device pointers;
     the trailing `stream` parameter is appended automatically.  Raises on a non-zero hipError_t."""

@@ -33,25 +33,7 @@ __global__ void affine_gather_kernel(const float* __restrict__ data, const int* 
     out[(size_t)b * per_sample + e] = (1.f - ar) * ((1.f - ac) * v00 + ac * v01) + ar * ((1.f - ac) * v10 + ac * v11);
 }
 
-// Small host -> device uploads (random draws, pool indices, rotation matrices: ~25 per iteration) as a KERNEL on the compute stream that reads
-// the pinned host buffer directly.  hipMemcpyAsync runs them on the runtime's blit queue: every upload then costs a cross-queue barrier on both
-// sides (~100 us of idle GPU around a 3 us copy -- `profiles/r03_gpu_gaps_*`: copy -> sampling_kl_fwd 4 x 107 us per iteration).
-__global__ void upload_words_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-
 extern "C" {
-
-// src_host: device-accessible pinned host memory (hipHostMalloc / torch pin_memory), nwords 4-byte words; the caller keeps src_host
-// unchanged until the launch has run (an event recorded after it)
-int mmseg_upload_words(const void* src_host, void* dst, long nwords, void* stream) {
-    if (nwords <= 0) return 0;
-    if (src_host == nullptr || dst == nullptr) return (int)hipErrorInvalidValue;
-    long blocks = (nwords + 255) / 256;
-    if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(upload_words_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)src_host, (unsigned*)dst, nwords);
-    return MMSEG_CHECK_LAUNCH();
-}
 
 // data [N,H,W,C] (N > max(rows)), rows [B] int32 or nullptr (= identity), mat [B,6], out [B,H,W,C]
 int mmseg_affine_gather(const float* data, const int* rows, const float* mat, float* out, int B, int H, int W, int C, int order,

@@ -17,7 +17,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import ops, _native
+from . import ops
 from .parallel import dp
 
 _DEVICE = None
@@ -268,44 +268,9 @@ def host_to_device(a, device, dtype=np.float32):
     if device.type != 'cuda':
         return torch.from_numpy(a).to(device)
     src = torch.from_numpy(a)
-    if 0 < a.nbytes <= _UPLOAD_MAX_BYTES and a.nbytes % 4 == 0 and not torch.cuda.is_current_stream_capturing():
-        return _upload_small(src, device)
     staged = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
     staged.copy_(src)
     return staged.to(device, non_blocking=True)
-
-
-_UPLOAD_MAX_BYTES = 1 << 16
-_UPLOAD_SLOTS = 16
-_upload_rings = {}       # (device index, size class) -> {'slots': [(pinned uint8 buffer, event | None)], 'next': int}
-
-
-def _upload_small(src, device):
-    """A small upload as a kernel on the compute stream reading a pinned staging slot (csrc/augment.hip: mmseg_upload_words) instead of a
-    hipMemcpyAsync on the runtime's blit queue, whose cross-queue barriers leave the GPU idle for ~100 us around a 3 us copy.  Staging
-    slots are recycled round-robin; a slot is rewritten only after the event recorded behind its last upload has completed."""
-    nbytes = src.numel() * src.element_size()
-    cls = max(256, 1 << (nbytes - 1).bit_length())
-    dev = device if device.index is not None else torch.device('cuda', torch.cuda.current_device())
-    ring = _upload_rings.setdefault((dev.index, cls), {'slots': [], 'next': 0})
-    if len(ring['slots']) < _UPLOAD_SLOTS:
-        ring['slots'].append([torch.empty(cls, dtype=torch.uint8, pin_memory=True), None])
-        i = len(ring['slots']) - 1
-    else:
-        i = ring['next']
-        ring['next'] = (i + 1) % _UPLOAD_SLOTS
-    buf, ev = ring['slots'][i]
-    if ev is not None:
-        ev.synchronize()                  # (long done in practice: the host is never 16 uploads of one size ahead)
-    buf[:nbytes].copy_(src.reshape(-1).view(torch.uint8))
-    out = torch.empty(src.shape, dtype=src.dtype, device=dev)
-    with torch.cuda.device(dev):
-        _native.launch_raw('mmseg_upload_words', dev, buf.data_ptr(), out.data_ptr(), nbytes // 4)
-        if ev is None:
-            ev = torch.cuda.Event()
-            ring['slots'][i][1] = ev
-        ev.record(torch.cuda.current_stream(dev))
-    return out
 
 
 def to_device(x, device):

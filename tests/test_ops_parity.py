@@ -579,33 +579,3 @@ def test_training_iterations_with_batched_weight_images_are_bitwise_the_lazy_one
     assert na > 20                                   # the images were registered (and refreshed in batches)
     assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
 
-
-@pytest.mark.gpu
-def test_small_uploads_through_the_pinned_ring_keep_their_values():
-    """nn.host_to_device: uploads up to 64 KB run as a kernel that reads a recycled pinned staging slot -- many more uploads than slots,
-    of one size class and of mixed sizes / dtypes, queued without synchronising in between, must all arrive intact"""
-    from multimodal_segmentation_amd import nn
-    dev = torch.device('cuda', 0)
-    rng = np.random.RandomState(5)
-    big = torch.randn(4096, 4096, device=dev)
-    sent, got = [], []
-    for i in range(200):
-        if i % 50 == 0:
-            big = big @ big * 1e-4            # keep the stream busy so that the uploads queue up behind real work
-        if i % 3 == 0:
-            a = rng.randint(0, 1 << 40, size=rng.randint(1, 40)).astype(np.int64)
-            t = nn.host_to_device(a, dev, np.int64)
-        elif i % 3 == 1:
-            a = rng.randn(4, 8).astype(np.float32)                       # one size class, more uploads than slots
-            t = nn.host_to_device(a, dev)
-        else:
-            a = rng.randn(rng.randint(1, 16000)).astype(np.float32)      # up to 64 KB
-            t = nn.host_to_device(a, dev)
-        sent.append(a)
-        got.append(t)
-    torch.cuda.synchronize()
-    for a, t in zip(sent, got):
-        assert t.dtype == (torch.int64 if a.dtype == np.int64 else torch.float32) and tuple(t.shape) == a.shape
-        assert np.array_equal(t.cpu().numpy(), a)
-    large = rng.randn(70000).astype(np.float32)                          # above the limit: the asynchronous copy path
-    assert np.array_equal(nn.host_to_device(large, dev).cpu().numpy(), large)
