@@ -5,7 +5,6 @@ updated with the axpby kernel; `get_clone_model()` builds (once) a second model 
 the averaged weights into it -- validation, testing and checkpoints use these clones (dafnet_executor.py:286-335)."""
 import logging
 
-import torch
 
 from .. import ops
 

@@ -8,7 +8,6 @@ sub-model cut at layer `z_mean` (models/dafnet.py:126).
 import logging
 
 import numpy as np
-import torch
 
 from .. import graphs, nn, ops
 from ..utils.rng import global_rng

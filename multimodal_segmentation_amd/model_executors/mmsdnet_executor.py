@@ -15,8 +15,6 @@ import logging
 import numpy as np
 import torch
 
-from .. import nn
-from ..utils import data_utils
 from ..utils.distributions import NormalDistribution
 from .dafnet_executor import DAFNetExecutor, _dev
 
