@@ -1,4 +1,4 @@
-"""Data-parallel path on CPU: world_size 2 over gloo with the TEST-ONLY kernel stand-in.
+"""Data-parallel path on CPU: world_size 2 (and full iterations at 4 and 8) over gloo with the TEST-ONLY kernel stand-in.
 
   * the discriminator trainers contain no BatchNorm, so 2 ranks x batch 1 must reproduce the single-process step on
     the concatenated batch 2 (gradient all-reduce mean == global-batch gradient);
@@ -201,3 +201,62 @@ def _single_process_reference(res):
             np.abs(res[0][4] - gref).max(), np.abs(gref).max())
     # after one Adam step |delta| = lr wherever the gradient is not ~0: compare the step direction
     assert np.abs(res[0][1] - ref).max() < 2.5e-4 * 1e-0 * 0 + 2e-6, 'DP D step differs from the global-batch step'
+
+
+def _worker4(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(2 if world <= 4 else 1)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        conf, model, Hh = _build()
+        from multimodal_segmentation_amd.parallel import dp
+        from multimodal_segmentation_amd.model_executors.dafnet_executor import DAFNetExecutor
+        dp.enable(True)
+        gens = model._generator_models()
+        all_models = gens + [model.D_Mask, model.D_Image1, model.D_Image2]
+        dp.broadcast_models(all_models)
+        conf.batch_size = 1
+        ex = DAFNetExecutor(conf, model)
+        ex.init_train_data(device_resident=False, slices_per_volume=1)
+        ok0, _ = dp.replicas_identical(all_models)
+        dp.counters(reset=True)
+        losses = {n: [] for n in ex.get_loss_names()}
+        for _ in range(2):
+            ex.train_batch(losses)
+        cnt = dp.counters()
+        ok1, cs = dp.replicas_identical(all_models)
+        first = float(losses[ex.get_loss_names()[0]][0])
+        q.put((rank, dict(ok0=ok0, ok1=ok1, steps=cnt['steps'], collectives=cnt['collectives'], overlapped=cnt['overlapped'],
+                          finite=all(np.isfinite(float(v)) for k in losses for v in losses[k]), n_gens=len(gens), checksum=cs[:4], first=first)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as exc:
+        import traceback
+        q.put((rank, 'error', traceback.format_exc(), repr(exc)))
+        raise
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world', [4, 8])
+def test_dp_gloo_full_iterations_keep_the_replicas_identical(world):
+    """Four and eight ranks (the driver scales to 2, 4 and 8): two full DAFNet iterations through the executor on per-rank batches -- rank-offset
+    data and noise seeds, one collective per arena and trainer step averaged over all ranks -- leave bit-identical replicas everywhere;
+    the ranks did see different data (their first losses differ)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=800) for _ in range(world)]
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == 'error'), r[2]
+    res = sorted(res, key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, f in res:
+        assert f['ok0'] and f['ok1'] and f['finite'], f
+        assert f['steps'] == 10 and f['collectives'] == 2 * (f['n_gens'] + 4) and f['overlapped'] == 2 * f['n_gens'], f
+        assert f['checksum'] == res[0][1]['checksum']
+    assert len({round(f['first'], 6) for _, f in res}) > 1, 'every rank reported the same first loss: the ranks saw the same batch'
