@@ -17,8 +17,13 @@ step lives in device memory the recorded kernels read:
 Python-side effects of a step (optimiser iteration count, weight / BatchNorm-state version counters that invalidate cached weight
 images) are repeated by the replay wrapper.  Results are bit-identical to the eager path (`tests/test_graph_capture.py`).
 Not used under data parallelism (the RCCL all-reduces issued during backward are left out of captures)."""
+import itertools
+import weakref
+
 import numpy as np
 import torch
+
+_serial = itertools.count(1)
 
 WARMUP = 2          # eager steps before the recording (allocations, workspaces and caches reach their steady state)
 
@@ -119,7 +124,10 @@ class FitGraph(object):
     """the recorded step of one trainer for one call signature"""
 
     def __init__(self, trainer):
+        from . import ops
         self.t = trainer
+        self.uid = next(_serial)       # names the scratch buffers the recording owns (ops._sid); never reused, unlike id()
+        weakref.finalize(self, ops.release_graph_workspaces, self.uid)
         self.calls = 0
         self.mode = None
         self.draws, self.draw_i = [], 0

@@ -11,7 +11,9 @@ kernel and the data-parallel all-reduce therefore work on whole arenas (one laun
 Weights are NOT autograd leaves: the autograd tape only carries activation gradients, and the kernels accumulate
 weight gradients straight into the gradient arena.
 """
+import itertools
 import math
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -86,11 +88,15 @@ def initialise(rng, shape, kind):
     raise ValueError(kind)
 
 
+_serial = itertools.count(1)      # uids of models and parameters: cache keys that are never reused (unlike id())
+
+
 class Param(object):
-    __slots__ = ('name', 'shape', 'init', 'trainable', 'data', 'grad', 'owner', 'offset')
+    __slots__ = ('name', 'shape', 'init', 'trainable', 'data', 'grad', 'owner', 'offset', 'uid')
 
     def __init__(self, name, shape, init, trainable=True):
         self.name, self.shape, self.init, self.trainable = name, tuple(shape), init, trainable
+        self.uid = next(_serial)
         self.data = self.grad = self.owner = None
         self.offset = 0
 
@@ -114,6 +120,8 @@ class Model(object):
 
     def __init__(self, name):
         self.name = name
+        self.uid = next(_serial)
+        weakref.finalize(self, ops.evict_owner, self.uid)      # the cached images of a dead model leave HBM with it
         self.trainable = True
         self.params = OrderedDict()
         self.arena = self.grad_arena = self.state_arena = None
@@ -154,7 +162,6 @@ class Model(object):
             else:
                 p.data = self.state_arena[p.offset:p.offset + p.numel].view(p.shape)
         self.device = device
-        ops.bump_weight_version()      # parameter objects (cache keys of the weight re-layouts) may recycle ids
         return self
 
     # ---- keras.Model surface -------------------------------------------------------------------------------
@@ -310,7 +317,7 @@ def conv(m, name, x, stride=1, padding='same', act=None, alpha=0.0, x2=None, ups
     b = m.params.get(name + '/bias')
     return ops.conv2d(x, w.data, b.data if b is not None else None, stride, padding, act, alpha, x2, upsample,
                       wgrad=w.g(), bgrad=b.g() if (b is not None and bias_grad) else None, anchor=anchor(x.device),
-                      wkey=(id(w), id(w.owner)), out_dtype=out_dtype)
+                      wkey=(w.uid, w.owner.uid), out_dtype=out_dtype)
 
 
 def conv_pair(m, name_a, name_b, x, out_dtype=torch.float32):
@@ -319,7 +326,7 @@ def conv_pair(m, name_a, name_b, x, out_dtype=torch.float32):
     wa, ba = m.params[name_a + '/kernel'], m.params[name_a + '/bias']
     wb, bb = m.params[name_b + '/kernel'], m.params[name_b + '/bias']
     grads = (wa.g(), ba.g(), wb.g(), bb.g())
-    return ops.conv2d_pair(x, wa.data, ba.data, wb.data, bb.data, grads, anchor=anchor(x.device), wkey=(id(wa), id(wa.owner)),
+    return ops.conv2d_pair(x, wa.data, ba.data, wb.data, bb.data, grads, anchor=anchor(x.device), wkey=(wa.uid, wa.owner.uid),
                            out_dtype=out_dtype)
 
 
@@ -354,7 +361,7 @@ def conv_bn(m, cname, bname, x, training, relu=False, x2=None, upsample=False, y
         return bn(m, bname, l, training, relu=relu, out_dtype=bn_dt)
     return ops.conv2d_bn_infer(x, w.data, b.data if b is not None else None, m.params[bname + '/gamma'].data,
                                m.params[bname + '/beta'].data, m.params[bname + '/moving_mean'].data,
-                               m.params[bname + '/moving_variance'].data, relu=relu, x2=x2, upsample=upsample, wkey=(id(w), id(w.owner)),
+                               m.params[bname + '/moving_variance'].data, relu=relu, x2=x2, upsample=upsample, wkey=(w.uid, w.owner.uid),
                                out_dtype=bn_dt)
 
 
@@ -412,11 +419,11 @@ class Adam(object):
             self.iterations += 1
         lr_t = self._lr_t() if lr_dev is None else lr_dev
         for m in models:
-            st = self.state.get(id(m))
+            st = self.state.get(m.uid)
             if st is None:
                 st = (ops.fill_(torch.empty_like(m.arena), 0.0), ops.fill_(torch.empty_like(m.arena), 0.0))
-                self.state[id(m)] = st
-            ops.adam_step(m.arena, m.grad_arena, st[0], st[1], lr_t, self.beta_1, self.beta_2, self.epsilon, owner=id(m))
+                self.state[m.uid] = st
+            ops.adam_step(m.arena, m.grad_arena, st[0], st[1], lr_t, self.beta_1, self.beta_2, self.epsilon, owner=m.uid)
 
 
 class History(object):

@@ -26,7 +26,7 @@ def _sid(device):
     from . import graphs
     st = graphs._recording
     if st is not None and st.mode == 'capture':
-        return ('graph', id(st))       # a recorded step owns its scratch: torch records every graph on one shared capture stream,
+        return ('graph', st.uid)       # a recorded step owns its scratch: torch records every graph on one shared capture stream,
                                        # and two recorded steps may later be replayed on concurrent streams
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -143,10 +143,10 @@ _bn_state_version = [0]      # bumped whenever BatchNorm moving statistics may h
 _bnfold_cache = {}
 
 
-_owner_version = {}          # id(nn.Model) -> version of that model's weights (bumped by its optimiser steps only)
+_owner_version = {}          # nn.Model.uid -> version of that model's weights (bumped by its optimiser steps only)
 
 
-_wprep_batch = {}            # id(nn.Model) -> {'ents': {cache key: (src ptr, image, taps, Cin, Cout, mode, wkey)}, 'table': tensor | None, 'blocks': int}
+_wprep_batch = {}            # nn.Model.uid -> {'ents': {cache key: (src ptr, image, taps, Cin, Cout, mode, wkey)}, 'table': tensor | None, 'blocks': int}
 _wprep_batch_on = [True]     # False: every image is re-laid out lazily by its own launch again (tests compare the two)
 
 
@@ -198,8 +198,65 @@ def bump_weight_version(owner=None):
     _bn_state_version[0] += 1
 
 
+def _key_owner(key):
+    """Model.uid a cache key belongs to, or None (keys start with the wkey = (Param.uid | ('pair', Param.uid), Model.uid))"""
+    wk = key[0]
+    return wk[1] if isinstance(wk, tuple) and len(wk) == 2 else None
+
+
+def evict_owner(owner):
+    """Drop every cached weight image / fused operand / BatchNorm fold of the model with this uid (nn.Model registers this as its
+    finaliser): a process that builds many models does not keep the images of the dead ones in HBM."""
+    for cache in (_wprep_cache, _pair_cache, _bnfold_cache):
+        for k in [k for k in cache if _key_owner(k) == owner]:
+            del cache[k]
+    _wprep_batch.pop(owner, None)
+    _owner_version.pop(owner, None)
+
+
+def release_caches(workspaces=True):
+    """Forget every cached weight image, fused operand and BatchNorm fold (they are rebuilt on demand) and, optionally, the
+    grow-only scratch buffers of all streams.  Must not be called while a recorded hipGraph that owns scratch is alive."""
+    _wprep_cache.clear()
+    _pair_cache.clear()
+    _bnfold_cache.clear()
+    _wprep_batch.clear()
+    if workspaces:
+        _workspaces.clear()
+
+
+def release_graph_workspaces(uid):
+    """the scratch buffers a recorded step owned (graphs.FitGraph registers this as its finaliser)"""
+    sid = ('graph', uid)
+    for k in [k for k in _workspaces if k[2] == sid]:
+        del _workspaces[k]
+    for cache in (_wprep_cache, _pair_cache, _bnfold_cache):       # ... and the weight images written inside the recording
+        for k in [k for k in cache if k[-1] == sid]:
+            del cache[k]
+    for b in _wprep_batch.values():
+        stale = [k for k in b['ents'] if k[-1] == sid]
+        for k in stale:
+            del b['ents'][k]
+        if stale:
+            b['table'] = None
+
+
+def cache_footprint():
+    """(entries, bytes) held by the caches and the scratch buffers -- for leak checks"""
+    n = b = 0
+    for cache in (_wprep_cache, _pair_cache, _bnfold_cache):
+        for ent in cache.values():
+            for t in ent[1:]:
+                if isinstance(t, torch.Tensor):
+                    n, b = n + 1, b + t.numel() * t.element_size()
+    for t in _workspaces.values():
+        n, b = n + 1, b + t.numel() * t.element_size()
+    return n, b
+
+
 def _wver(wkey):
-    """version stamp of a cached image: (global version, version of the owning model); wkey = (id(param), id(owner model))"""
+    """version stamp of a cached image: (global version, version of the owning model); wkey = (Param.uid, Model.uid) -- serial
+    numbers that are never reused (object ids are recycled by the interpreter, device addresses by the caching allocator)"""
     if isinstance(wkey, tuple):
         return (_weight_version[0], _owner_version.get(wkey[1], 0))
     return (_weight_version[0], 0)
@@ -973,12 +1030,26 @@ _pair_cache = {}
 
 
 def _pair_operands(wa, ba, wb, bb, wkey):
-    """[KH, KW, Cin, Ca + Cb] kernel and [Ca + Cb] bias of the fused convolution: the two Keras kernels side by side (a copy per weight
-    version into buffers that live as long as the layer, so that the cached weight images keyed on them stay valid)"""
+    """[KH, KW, Cin, Ca + Cb] kernel and [Ca + Cb] bias of the fused convolution: the two Keras kernels side by side.  Parameters of
+    an nn.Model (`wkey`): a copy per weight version into buffers that live as long as the layer, so that the cached weight images
+    keyed on them stay valid.  Anonymous weights (`wkey` None) are NEVER cached -- neither an address nor an object id identifies a
+    tensor once the caching allocator has recycled it (round-3 review: a later weight of the same byte size got the previous
+    layer's operands): they are concatenated on every call into scratch of the stream, like _wprep does."""
     KH, KW, Cin, Ca = wa.shape
     Cb = wb.shape[3]
-    key = (wkey, wa.data_ptr(), _sid(wa.device))
+    assert wb.shape == (KH, KW, Cin, Cb) and ba.numel() == Ca and bb.numel() == Cb
+    nw, nb = KH * KW * Cin * (Ca + Cb), Ca + Cb
+    if wkey is None:
+        buf = _ws('pair_operands', nw + nb + 4, wa.device)
+        wcat = buf[:nw].view(KH, KW, Cin, Ca + Cb)
+        bcat = buf[(nw + 3) // 4 * 4:(nw + 3) // 4 * 4 + nb]
+        N.call('mmseg_concat_cols', wa, wb, wcat, KH * KW * Cin, Ca, Cb)
+        N.call('mmseg_concat_cols', ba, bb, bcat, 1, Ca, Cb)
+        return wcat, bcat
+    key = (wkey, wa.data_ptr(), wb.data_ptr(), _sid(wa.device))
     ent = _pair_cache.get(key)
+    if ent is not None and (tuple(ent[1].shape) != (KH, KW, Cin, Ca + Cb) or ent[2].numel() != nb):
+        ent = None           # never hand out operands of another geometry
     if ent is not None and ent[0] == _wver(wkey):
         return ent[1], ent[2]
     if ent is None:
@@ -1012,7 +1083,8 @@ class _Conv2dPair(torch.autograd.Function):
         y = _new((B, H, W, Cout), x, out_dtype if wt is not None else torch.float32)     # (16-bit outputs: fast path only)
         _conv_fwd_raw(x, None, wcat, wt, bcat, y, None, B, H, W, Cin, 0, H, W, Cout, KH, KW, 1, KH // 2, KW // 2, 0, 0, 0, 0.0, 0)
         ctx.geom = (B, H, W, Cin, Ca, Cb, KH, KW)
-        ctx.grads, ctx.pkey, ctx.wcat = grads, pkey, wcat
+        ctx.grads, ctx.pkey = grads, pkey
+        ctx.operands = (wa, ba, wb, bb, wkey)     # plain (non-leaf) weight views: not tracked by autograd
         ctx.save_for_backward(x)
         return y
 
@@ -1039,11 +1111,13 @@ class _Conv2dPair(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _new((B, H, W, Cin), dy, x.dtype)          # a gradient is stored like its tensor
+            # (a model's operands come out of the cache; anonymous ones are concatenated again: their scratch may have been reused)
+            wcat = _pair_operands(*ctx.operands)[0]
             if N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0):
-                wf, wt = None, _wprep(ctx.wcat, KH, KW, Cin, Cout, 1, ctx.pkey)
+                wf, wt = None, _wprep(wcat, KH, KW, Cin, Cout, 1, ctx.pkey)
             else:
-                wf, wt = _ws('wflip', ctx.wcat.numel(), dy.device)[:ctx.wcat.numel()], None
-                N.call('mmseg_conv2d_wflip', ctx.wcat, wf, KH, KW, Cin, Cout)
+                wf, wt = _ws('wflip', wcat.numel(), dy.device)[:wcat.numel()], None
+                N.call('mmseg_conv2d_wflip', wcat, wf, KH, KW, Cin, Cout)
             _conv_fwd_raw(dy, None, wf, wt, None, dx, None, B, H, W, Cout, 0, H, W, Cin, KH, KW, 1, KH - 1 - KH // 2, KW - 1 - KW // 2,
                           0, 0, 0, 0.0, 0)
         return (dx,) + (None,) * 8

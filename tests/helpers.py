@@ -187,7 +187,7 @@ def product_state(model):
         opt = getattr(model, attr).optimizer
         ms, vs = {}, {}
         for prefix, m in items:
-            st = opt.state.get(id(m))
+            st = opt.state.get(m.uid)
             if st is None:
                 continue
             for p in m.params.values():
@@ -221,7 +221,7 @@ def load_oracle_state(model, orc):
                 if p.trainable and n in oad.m:
                     st[0][p.offset:p.offset + p.numel].copy_(oad.m[n].detach().to(torch.float32).reshape(-1).to(m.arena.device))
                     st[1][p.offset:p.offset + p.numel].copy_(oad.v[n].detach().to(torch.float32).reshape(-1).to(m.arena.device))
-            opt.state[id(m)] = st
+            opt.state[m.uid] = st
 
 
 def sharpen_anatomy_heads(model, factor=40.0, theta_std=0.002, seed=3):

@@ -186,6 +186,67 @@ def test_spade_gamma_beta_as_one_convolution(B, H, W, Cin, f, alpha, device):
     check(f_prod, f_ref, [a, x, wg, bg, wb, bb], device, param_idx=(2, 3, 4, 5))
 
 
+def test_anonymous_pair_operands_are_never_cached(device):
+    """regression (round-3 driver run): ops.conv2d_pair with wkey=None cached the concatenated gamma|beta operands under the ADDRESS of
+    the first kernel.  Free that kernel, allocate a DIFFERENT one of the same byte size (the caching allocator hands out the same block)
+    and call again: the result must be the new weights' -- also when every shape matches, where the stale entry used to give wrong
+    numbers without any error -- and a kernel of another geometry in the same block must not trip over the old operands."""
+    B, H, W, Cin, f = 1, 8, 8, 64, 64
+    a = rnd(B, H, W, Cin, seed=1).to(device)
+
+    def run(seed, Cin_, f_):
+        x = a if Cin_ == Cin else rnd(B, H, W, Cin_, seed=9).to(device)
+        wg = rnd(3, 3, Cin_, f_, seed=seed, scale=0.05).to(device)
+        wb = rnd(3, 3, Cin_, f_, seed=seed + 1, scale=0.05).to(device)
+        bg, bb = rnd(f_, seed=seed + 2).to(device), rnd(f_, seed=seed + 3).to(device)
+        ptr = wg.data_ptr()
+        with torch.no_grad():
+            y = P.conv2d_pair(x, wg, bg, wb, bb, wkey=None)
+        ref = torch.cat([O.conv2d(x.cpu().double(), wg.cpu().double(), bg.cpu().double()),
+                         O.conv2d(x.cpu().double(), wb.cpu().double(), bb.cpu().double())], -1)
+        _close(y, ref, 'pair(seed %d)' % seed)
+        out = y.cpu()
+        del wg, wb, bg, bb, y
+        return out, ptr
+
+    y1, p1 = run(10, Cin, f)
+    y2, p2 = run(20, Cin, f)                   # same byte size, other values
+    assert (y1 - y2).abs().max().item() > 1e-2, 'second call returned the first weights\' result'
+    run(30, 128, 32)                           # 3*3*128*32 floats = the same 147 456 bytes, other geometry (the driver's failing pair)
+    if device == 'cuda':
+        assert p1 == p2, 'allocator did not recycle the block: the regression is not exercised'
+    assert not P._pair_cache, 'anonymous operands must not enter the cache'
+
+
+def test_model_caches_are_evicted_with_the_model(device):
+    """cached weight images / fused operands are keyed on never-reused serial numbers and leave HBM when their model dies"""
+    import gc
+    from multimodal_segmentation_amd import nn
+    nn.set_default_device(device)
+    try:
+        def build_and_run():
+            m = nn.Model('evict_probe')
+            nn.conv_params(m, 'g', 3, 64, 64)
+            nn.conv_params(m, 'b', 3, 64, 64)
+            nn.conv_params(m, 'c', 3, 64, 64)
+            m.finalize(np.random.RandomState(0), torch.device(device))
+            x = rnd(1, 8, 8, 64).to(device)
+            with torch.no_grad():
+                nn.conv_pair(m, 'g', 'b', x)
+                nn.conv(m, 'c', x)
+            return m.uid
+        before = (len(P._wprep_cache), len(P._pair_cache))
+        uid = build_and_run()
+        gc.collect()
+        owners = [P._key_owner(k) for cache in (P._wprep_cache, P._pair_cache, P._bnfold_cache) for k in cache]
+        assert uid not in owners and uid not in P._wprep_batch and uid not in P._owner_version
+        assert (len(P._wprep_cache), len(P._pair_cache)) == before
+        uid2 = build_and_run()
+        assert uid2 != uid
+    finally:
+        nn.set_default_device('cuda' if torch.cuda.is_available() else 'cpu')
+
+
 @pytest.mark.parametrize('shape,relu', [((2, 16, 16, 64), True), ((3, 8, 8, 128), False), ((2, 32, 32, 64), True)])
 def test_batchnorm_train(shape, relu, device):
     C = shape[-1]
