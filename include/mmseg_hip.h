@@ -200,6 +200,23 @@ int mmseg_bn_bwd_t(const void* dy, const void* y, const void* x, const float* ga
 int mmseg_maxpool2_fwd_t(const void* x, void* y, int B, int H, int W, int C, int h, void* stream);
 int mmseg_maxpool2_bwd_t(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, int h, void* stream);
 int mmseg_upsample2_bwd_t(const void* dy, void* dx, int B, int H, int W, int C, int h, void* stream);
+/* dx = gradient of MaxPooling2D(2) + add (add may be NULL): the down-path activation of models/unet.py:39-51 feeds the pooling AND the
+ * skip Concatenate (models/unet.py:69-84); both gradients in one pass instead of the autograd engine's separate addition */
+int mmseg_maxpool2_bwd_add_t(const void* x, const void* y, const void* dy, const void* add, void* dx, int B, int H, int W, int C, int h,
+                             void* stream);
+/* out = p0 + ... + p(n-1), 1 <= n <= 8, tensors of `numel` elements with element code h: the sum of the gradients of a tensor with
+ * several consumers (keras / TF add them inside the backward graph, e.g. the anatomy s feeding 7 layers in models/dafnet.py:163-222) */
+int mmseg_sum_n_t(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, const void* p5, const void* p6,
+                  const void* p7, int n, void* out, long numel, int h, void* stream);
+/* out = concatenation of n <= 8 equally sized contiguous parts of `words` 4-byte words along the leading axis; NULL part = zeros
+ * (batched calls of per-sample components: the 6 decodings / 4 D_Mask passes of models/dafnet.py:187-215, the pools of
+ * model_executors/dafnet_executor.py:524-570) */
+int mmseg_cat_words(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, const void* p5, const void* p6,
+                    const void* p7, int n, void* out, long words, void* stream);
+/* out[r] = src[idx[r]], rows of `words` 4-byte words (utils/data_utils.py sample(): np.random.choice rows of a fake pool) */
+int mmseg_gather_rows(const void* src, const long long* idx, void* out, int rows, long words, int src_rows, void* stream);
+/* base_executor.py:83-87 add_residual on the device: out[M][C+1] = masks + background channel */
+int mmseg_add_residual(const float* msk, float* out, long M, int C, void* stream);
 /* dx = dy * act'(y) of a convolution's fused activation (y = its output), tensors stored with element code h (0 fp32, 1 bf16, 2 fp16);
  * with bias_grad != NULL also the bias gradient bias_grad[c] (+)= sum_m dx[m][c] in the same pass (C % 64 == 0, ws =
  * mmseg_colsum_workspace_floats(M, C) floats) -- one pass instead of mmseg_act_bwd + mmseg_colsum */

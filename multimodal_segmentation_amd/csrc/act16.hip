@@ -151,7 +151,7 @@ __global__ void maxpool16_fwd_kernel(const void* __restrict__ x, void* __restric
 // gradient goes to the FIRST maximum in row-major window order (as in pointwise.hip)
 template <int H>
 __global__ void maxpool16_bwd_kernel(const void* __restrict__ x, const void* __restrict__ y, const void* __restrict__ dy,
-                                     void* __restrict__ dx, int B, int Hh, int W, int C4) {
+                                     void* __restrict__ dx, int B, int Hh, int W, int C4, const void* __restrict__ add = nullptr) {
     const int Ho = Hh / 2, Wo = W / 2;
     const long n = (long)B * Ho * Wo * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -170,6 +170,9 @@ __global__ void maxpool16_bwd_kernel(const void* __restrict__ x, const void* __r
             const bool cc = !a && !bb && v10[e] == m[e];
             const bool dd = !a && !bb && !cc;
             g00[e] = a ? g[e] : 0.f; g01[e] = bb ? g[e] : 0.f; g10[e] = cc ? g[e] : 0.f; g11[e] = dd ? g[e] : 0.f;
+        }
+        if (add != nullptr) {      // the tensor has a second consumer (UNet skip): its gradient is added in the same pass
+            g00 += ld4<H>(add, base); g01 += ld4<H>(add, base + o01); g10 += ld4<H>(add, base + o10); g11 += ld4<H>(add, base + o11);
         }
         st4<H>(dx, base, g00); st4<H>(dx, base + o01, g01); st4<H>(dx, base + o10, g10); st4<H>(dx, base + o11, g11);
     }
@@ -316,6 +319,78 @@ __global__ __launch_bounds__(256) void im2col8_kernel(const void* __restrict__ x
     }
 }
 
+// ---- fan-out gradients, batch concatenation, row gather (plumbing the autograd engine / torch.cat / index_select did with torch kernels) ----
+struct Ptr8 { const void* p[8]; };
+// out = p[0] + p[1] + ... + p[n-1] (left to right, fp32 accumulation), n4 groups of 4 elements + a scalar tail
+template <int H>
+__global__ __launch_bounds__(256) void sum_n_kernel(Ptr8 in, int n, void* __restrict__ out, long n4, long numel) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 acc = ld4<H>(in.p[0], i);
+        for (int k = 1; k < n; ++k) acc += ld4<H>(in.p[k], i);
+        st4<H>(out, i, acc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long i = n4 * 4; i < numel; ++i) {
+            float acc = ld1<H>(in.p[0], i);
+            for (int k = 1; k < n; ++k) acc += ld1<H>(in.p[k], i);
+            if constexpr (H == 0) reinterpret_cast<float*>(out)[i] = acc;
+            else if constexpr (H == 1) reinterpret_cast<__bf16*>(out)[i] = (__bf16)acc;
+            else reinterpret_cast<_Float16*>(out)[i] = (_Float16)acc;
+        }
+}
+// out[k * words .. (k + 1) * words) = p[k][0 .. words) in 4-byte words (a NULL part is written as zeros): concatenation of up to 8
+// equally sized contiguous tensors along the leading axis in ONE launch (type-agnostic: bytes are moved, nothing is computed)
+__global__ __launch_bounds__(256) void cat_words_kernel(Ptr8 in, int n, unsigned* __restrict__ out, long words) {
+    const long w4 = words / 4;
+    for (int k = 0; k < n; ++k) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(in.p[k]);
+        unsigned* dst = out + (long)k * words;
+        const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+        if (vec) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < w4; i += (long)gridDim.x * blockDim.x)
+                reinterpret_cast<u4*>(dst)[i] = src ? reinterpret_cast<const u4*>(src)[i] : u4{0u, 0u, 0u, 0u};
+            if (blockIdx.x == 0 && threadIdx.x == 0)
+                for (long i = w4 * 4; i < words; ++i) dst[i] = src ? src[i] : 0u;
+        } else {
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (long)gridDim.x * blockDim.x)
+                dst[i] = src ? src[i] : 0u;
+        }
+    }
+}
+// out[r] = src[idx[r]] for rows of `words` 4-byte words (index_select along the leading axis: sampling a fake pool)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned* __restrict__ src, const long long* __restrict__ idx,
+                                                          unsigned* __restrict__ out, int rows, long words, int src_rows) {
+    const bool vec = (words % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        long long s = idx[r];
+        if (s < 0 || s >= src_rows) continue;        // (the host validates the indices; never read out of range)
+        const unsigned* a = src + (long)s * words;
+        unsigned* o = out + (long)r * words;
+        if (vec) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < words / 4; i += (long)gridDim.x * blockDim.x)
+                reinterpret_cast<u4*>(o)[i] = reinterpret_cast<const u4*>(a)[i];
+        } else {
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (long)gridDim.x * blockDim.x) o[i] = a[i];
+        }
+    }
+}
+// out[m][0..C) = msk[m][0..C), out[m][C] = 1 unless some msk[m][c] == 1 exactly (model_executors/base_executor.py:83-87 of the
+// reference: the background channel appended to a batch of masks)
+__global__ __launch_bounds__(256) void add_residual_kernel(const float* __restrict__ msk, float* __restrict__ out, long M, int C) {
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        bool any = false;
+        for (int c = 0; c < C; ++c) {
+            const float v = msk[m * C + c];
+            out[m * (C + 1) + c] = v;
+            any = any || (v == 1.f);
+        }
+        out[m * (C + 1) + C] = any ? 0.f : 1.f;
+    }
+}
+
+
 static inline bool hcode_ok(int h) { return h >= 0 && h <= 2; }
 // (hx, hy) pairs that occur: a tensor is fp32 or THE 16-bit type of the run
 #define DISPATCH_HH(hx, hy, LAUNCH)                                              \
@@ -392,6 +467,52 @@ int mmseg_maxpool2_bwd_t(const void* x, const void* y, const void* dy, void* dx,
 #undef L
     return MMSEG_CHECK_LAUNCH();
 }
+// dx = (gradient of 2x2 max pooling) + add: a pooled tensor that also feeds a skip connection gets both gradients in one pass (the
+// autograd engine would add them with a separate kernel: one more read and write of the largest activations).  add may be NULL.
+int mmseg_maxpool2_bwd_add_t(const void* x, const void* y, const void* dy, const void* add, void* dx, int B, int H, int W, int C, int h,
+                             void* stream) {
+    if ((C & 3) || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+    const long n = (long)B * (H / 2) * (W / 2) * (C / 4);
+#define L(HH) hipLaunchKernelGGL((maxpool16_bwd_kernel<HH>), dim3(grid16(n)), dim3(256), 0, (hipStream_t)stream, x, y, dy, dx, B, H, W, C / 4, add)
+    DISPATCH_H(h, L);
+#undef L
+    return MMSEG_CHECK_LAUNCH();
+}
+
+int mmseg_sum_n_t(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, const void* p5, const void* p6,
+                  const void* p7, int n, void* out, long numel, int h, void* stream) {
+    if (n < 1 || n > 8 || numel < 0) return (int)hipErrorInvalidValue;
+    Ptr8 in = {{p0, p1, p2, p3, p4, p5, p6, p7}};
+    for (int k = 0; k < n; ++k) if (in.p[k] == nullptr) return (int)hipErrorInvalidValue;
+    const long n4 = numel / 4;
+#define L(HH) hipLaunchKernelGGL((sum_n_kernel<HH>), dim3(grid16(n4 + 1)), dim3(256), 0, (hipStream_t)stream, in, n, out, n4, numel)
+    DISPATCH_H(h, L);
+#undef L
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_cat_words(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, const void* p5, const void* p6,
+                    const void* p7, int n, void* out, long words, void* stream) {
+    if (n < 1 || n > 8 || words < 0) return (int)hipErrorInvalidValue;
+    Ptr8 in = {{p0, p1, p2, p3, p4, p5, p6, p7}};
+    hipLaunchKernelGGL(cat_words_kernel, dim3(grid16(words / 4 + 1)), dim3(256), 0, (hipStream_t)stream, in, n, (unsigned*)out, words);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_gather_rows(const void* src, const long long* idx, void* out, int rows, long words, int src_rows, void* stream) {
+    if (rows < 0 || words < 0) return (int)hipErrorInvalidValue;
+    if (rows == 0 || words == 0) return 0;
+    long bx = (words / 4 + 255) / 256;
+    if (bx < 1) bx = 1;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)bx, (unsigned)(rows < 4096 ? rows : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned*)src, idx, (unsigned*)out, rows, words, src_rows);
+    return MMSEG_CHECK_LAUNCH();
+}
+int mmseg_add_residual(const float* msk, float* out, long M, int C, void* stream) {
+    if (C < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_residual_kernel, dim3(grid16(M)), dim3(256), 0, (hipStream_t)stream, msk, out, M, C);
+    return MMSEG_CHECK_LAUNCH();
+}
+
 int mmseg_upsample2_bwd_t(const void* dy, void* dx, int B, int H, int W, int C, int h, void* stream) {
     if (C & 3) return (int)hipErrorInvalidValue;
     const long n = (long)B * H * W * (C / 4);

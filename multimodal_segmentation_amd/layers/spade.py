@@ -59,14 +59,17 @@ def _spade(m, name, anatomy_input, layer, act_alpha):
 
 def spade_block(m, n, anatomy_input, layer, fin, fout):
     """layers/spade.py:7-23"""
-    l2 = _spade(m, n + '_s0', anatomy_input, layer, 0.2)
+    layer = ops.Shared(layer, 2)                   # main branch + shortcut
+    l2 = _spade(m, n + '_s0', anatomy_input.use(), layer.use(), 0.2)
     l3 = nn.conv(m, n + '_c0', l2)
-    l5 = _spade(m, n + '_s1', anatomy_input, l3, 0.2)
+    l5 = _spade(m, n + '_s1', anatomy_input.use(), l3, 0.2)
     l6 = nn.conv(m, n + '_c1', l5)
     if fin != fout:
-        layer = _spade(m, n + '_ss', anatomy_input, layer, -1.0)
-        layer = nn.conv(m, n + '_cs', layer)
-    return ops.add(layer, l6)
+        sc = _spade(m, n + '_ss', anatomy_input.use(), layer.use(), -1.0)
+        sc = nn.conv(m, n + '_cs', sc)
+    else:
+        sc = layer.use()
+    return ops.add(sc, l6)
 
 
 def spade_decoder(m, conf, anatomy_input, modality_input):
@@ -74,6 +77,8 @@ def spade_decoder(m, conf, anatomy_input, modality_input):
     B = anatomy_input.shape[0]
     H, W = conf.input_shape[0], conf.input_shape[1]
     l = nn.dense(m, 'fc', modality_input).reshape(B, H // 32, W // 32, 128)
+    # every SPADE unit conditions on the anatomy (15 units): one alias per unit, their gradients are added by two launches
+    anatomy_input = ops.Shared(anatomy_input, sum(2 + (fin != fout) for fin, fout in SPADE_BLOCKS))
     for i, (fin, fout) in enumerate(SPADE_BLOCKS):
         if i > 0:
             l = ops.upsample2(l)

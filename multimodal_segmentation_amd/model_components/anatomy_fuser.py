@@ -20,9 +20,12 @@ class AnatomyFuser(nn.Model):
         self.output_shape = [(None,) + tuple(shp)] * 2
 
     def forward(self, anatomy1, anatomy2, training=False):
-        theta = stn_spline.locnet(self, anatomy1, anatomy2)
-        anatomy1_deformed = self.tps([anatomy1, theta])
-        anatomy_fused = ops.maximum(anatomy1_deformed, anatomy2)      # keras.layers.Maximum (anatomy_fuser.py:33)
+        a1 = ops.Shared(anatomy1, 2)       # localisation network + the warp itself
+        a2 = ops.Shared(anatomy2, 2)       # localisation network + the fusion
+        theta = stn_spline.locnet(self, a1.use(), a2.use())
+        d = ops.Shared(self.tps([a1.use(), theta]), 2)                # returned + fused
+        anatomy1_deformed = d.use()
+        anatomy_fused = ops.maximum(d.use(), a2.use())                # keras.layers.Maximum (anatomy_fuser.py:33)
         self.last_theta = theta
         return [anatomy1_deformed, anatomy_fused]
 

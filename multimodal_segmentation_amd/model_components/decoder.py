@@ -37,13 +37,14 @@ class Decoder(nn.Model):
 
     def _film_decoder(self, s, z):
         l = nn.conv(self, 'c0', s, act='leaky', alpha=0.3)
+        zs = ops.Shared(z, 8)          # z feeds the gamma and beta layers of all four FiLM layers
         for i in range(4):
             n = 'f%d' % i
-            l1 = nn.conv(self, n + '_c1', l, act='leaky', alpha=0.3)
-            l2 = nn.conv(self, n + '_c2', l1)
-            gamma = nn.dense(self, n + '_gamma', z, act='leaky', alpha=0.3)
-            beta = nn.dense(self, n + '_beta', z, act='leaky', alpha=0.3)
-            l = ops.film(l2, gamma, beta, res=l1, alpha=0.3)
+            l1 = ops.Shared(nn.conv(self, n + '_c1', l, act='leaky', alpha=0.3), 2)      # second convolution + residual
+            l2 = nn.conv(self, n + '_c2', l1.use())
+            gamma = nn.dense(self, n + '_gamma', zs.use(), act='leaky', alpha=0.3)
+            beta = nn.dense(self, n + '_beta', zs.use(), act='leaky', alpha=0.3)
+            l = ops.film(l2, gamma, beta, res=l1.use(), alpha=0.3)
         return l
 
     def forward(self, s, z, training=False):

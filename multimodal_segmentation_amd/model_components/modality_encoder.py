@@ -39,7 +39,10 @@ class ModalityEncoder(nn.Model):
             l = nn.conv(self, 'c%d' % i, l, stride=2, padding='valid', act='leaky', alpha=0.3)
         l = nn.dense(self, 'd0', l.reshape(l.shape[0], -1), act='leaky', alpha=0.3)
         # Enc_Modality_mu is the same network cut at z_mean (dafnet.py:126): the log-variance head is not evaluated there
-        return nn.dense(self, 'z_mean', l), (nn.dense(self, 'z_log_var', l) if want_logvar else None)
+        if not want_logvar:
+            return nn.dense(self, 'z_mean', l), None
+        l = ops.Shared(l, 2)           # both heads read it: their gradients are added by one launch in the backward pass
+        return nn.dense(self, 'z_mean', l.use()), nn.dense(self, 'z_log_var', l.use())
 
     def forward(self, s, x, training=False, eps=None, mu_only=False):
         z_mean, z_log_var = self._mean_logvar(s, x, want_logvar=not mu_only)

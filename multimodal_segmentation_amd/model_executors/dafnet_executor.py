@@ -15,7 +15,7 @@ import os
 import numpy as np
 import torch
 
-from .. import costs, nn
+from .. import costs, nn, ops
 from ..callbacks.swa import SWA
 from ..loaders import synthetic
 from ..model_components import anatomy_encoder, modality_encoder, anatomy_fuser, segmentor, decoder, balancer
@@ -312,8 +312,8 @@ class DAFNetExecutor(Executor):
                 return [x]
             return [x[..., i:i + 1].contiguous() if isinstance(x, torch.Tensor) else x[..., i:i + 1] for i in range(n_pairs)]
         x1_list, x2_list = split_images(x1_pairs), split_images(x2_pairs)
-        m1 = self._residual(m1_pairs[..., 0:nm])
-        m2 = self._residual(m2_pairs[..., 0:nm]) if m2_pairs is not None else None
+        m1 = self._residual(_first_channels(m1_pairs, nm))
+        m2 = self._residual(_first_channels(m2_pairs, nm)) if m2_pairs is not None else None
         batch_size = x1_list[0].shape[0]
         norm = NormalDistribution()
         z1 = norm.sample((batch_size, self.conf.num_z)).astype(np.float32)
@@ -383,9 +383,9 @@ class DAFNetExecutor(Executor):
         fake_s1 = m.Encoders_Anatomy[0].predict(x1)
         fake_s2 = m.Encoders_Anatomy[1].predict(x2)
         B = fake_s1.shape[0]
-        sd = m.Anatomy_Fuser.predict([torch.cat([fake_s2, fake_s1], 0), torch.cat([fake_s1, fake_s2], 0)])[0]
+        sd = m.Anatomy_Fuser.predict([ops.cat_batch([fake_s2, fake_s1]), ops.cat_batch([fake_s1, fake_s2])])[0]
         s2_def, s1_def = sd[:B], sd[B:]
-        masks = m.Segmentor.predict(torch.cat([fake_s1, s2_def, fake_s2, s1_def], 0))[..., 0:nm].contiguous()
+        masks = ops.slice_channels(m.Segmentor.predict(ops.cat_batch([fake_s1, s2_def, fake_s2, s1_def])), 0, nm)
         return masks[:2 * B], masks[2 * B:]      # [m(s1); m(s2_def)], [m(s2); m(s1_def)]
 
     def image_pools(self, x1, x2, eps1=None, eps2=None):
@@ -395,26 +395,26 @@ class DAFNetExecutor(Executor):
         s1 = m.Encoders_Anatomy[0].predict(x1)
         s2 = m.Encoders_Anatomy[1].predict(x2)
         B = s1.shape[0]
-        sd = m.Anatomy_Fuser.predict([torch.cat([s1, s2], 0), torch.cat([s2, s1], 0)])[0]
+        sd = m.Anatomy_Fuser.predict([ops.cat_batch([s1, s2]), ops.cat_batch([s2, s1])])[0]
         s1_def, s2_def = sd[:B], sd[B:]
         z1, _ = m.Enc_Modality.predict([s1, x1], eps=eps1)
         z2, _ = m.Enc_Modality.predict([s2, x2], eps=eps2)
-        ys = m.Decoder.predict([torch.cat([s1, s2_def, s1_def, s2, s1_def, s2_def], 0), torch.cat([z1, z1, z1, z2, z2, z2], 0)])
+        ys = m.Decoder.predict([ops.cat_batch([s1, s2_def, s1_def, s2, s1_def, s2_def]), ops.cat_batch([z1, z1, z1, z2, z2, z2])])
         return ys[:3 * B], ys[3 * B:]
 
     def _sample(self, pool, batch_size):
         """utils.data_utils.sample: np.random.choice(len, size, replace=False), gathered on the device"""
         idx = data_utils.sample_indices(pool.shape[0], batch_size)
-        return pool.index_select(0, nn.host_to_device(idx, pool.device, np.int64))
+        return ops.gather_rows(pool, nn.host_to_device(idx, pool.device, np.int64))
 
     def train_batch_mask_discriminator(self, epoch_loss):
         """dafnet_executor.py:511-545"""
         nm = self.conf.num_masks
-        m1 = _dev(next(self.discriminator_masks), self.device)[..., 0:nm]
-        m2 = _dev(next(self.discriminator_masks), self.device)[..., 0:nm]
+        m1 = _first_channels(_dev(next(self.discriminator_masks), self.device), nm)
+        m2 = _first_channels(_dev(next(self.discriminator_masks), self.device), nm)
         x1, x2 = [_dev(next(gen), self.device) for gen in self.discriminator_image]
         mn = min(x1.shape[0], x2.shape[0], m1.shape[0], m2.shape[0])
-        x1, x2, m1, m2 = x1[:mn], x2[:mn], m1[:mn].contiguous(), m2[:mn].contiguous()
+        x1, x2, m1, m2 = x1[:mn], x2[:mn], m1[:mn], m2[:mn]
         pool1, pool2 = self.mask_pools(x1, x2)
         h = self.model.D_Mask_trainer.fit([m1, self._sample(pool1, mn)], [1.0, 0.0])
         epoch_loss['dis_M'].append(self._loss(h, 'loss'))
@@ -452,11 +452,19 @@ def _dev(x, device):
     return nn.to_device(x, device)
 
 
+def _first_channels(t, n):
+    """t[..., 0:n] as a contiguous array on whatever side t lives (a kernel of the library on the device, never a torch copy)"""
+    if t.shape[-1] == n:
+        return t
+    if isinstance(t, torch.Tensor):
+        return ops.slice_channels(t, 0, n)
+    return np.ascontiguousarray(t[..., 0:n])
+
+
 def _add_residual_device(m):
     """background = 1 except where some mask equals 1 exactly (base_executor.py:83-87; after the bilinear rotation the
     masks carry fractional edge values, which therefore count as background) -- pure data preparation on the device"""
-    res = 1.0 - (m == 1).any(-1, keepdim=True).to(m.dtype)
-    return torch.cat([m, res], -1).contiguous()
+    return ops.add_residual(m)
 
 
 def _f(v):

@@ -16,7 +16,8 @@ import numpy as np
 import torch
 
 from ..utils.distributions import NormalDistribution
-from .dafnet_executor import DAFNetExecutor, _dev
+from .. import ops
+from .dafnet_executor import DAFNetExecutor, _dev, _first_channels
 
 log = logging.getLogger('mmsdnet_executor')
 
@@ -159,14 +160,14 @@ class MMSDNetExecutor(DAFNetExecutor):
         for j in range(1, len(fake_s)):
             extra += m.Anatomy_Fuser.predict([fake_s[0], fake_s[j]])
         # inference-mode BatchNorm has no batch statistics: the segmentations are one batched call
-        return m.Segmentor.predict(torch.cat(fake_s + extra, 0))[..., 0:nm].contiguous()
+        return ops.slice_channels(m.Segmentor.predict(ops.cat_batch(fake_s + extra)), 0, nm)
 
     def train_batch_mask_discriminator(self, epoch_loss):
         nm = self.conf.num_masks
-        m = _dev(next(self.discriminator_masks), self.device)[..., 0:nm]
+        m = _first_channels(_dev(next(self.discriminator_masks), self.device), nm)
         x_list = [_dev(next(gen), self.device) for gen in self.discriminator_image]
         mn = min([x.shape[0] for x in x_list] + [m.shape[0]])
-        x_list, m = [x[:mn] for x in x_list], m[:mn].contiguous()
+        x_list, m = [x[:mn] for x in x_list], m[:mn]
         pool = self.mask_pool(*x_list)
         h = self.model.D_Mask_trainer.fit([m, self._sample(pool, mn)], [1.0, 0.0])
         epoch_loss['dis_M'].append(self._loss(h, 'D_Mask_loss'))

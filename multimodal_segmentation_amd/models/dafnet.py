@@ -113,32 +113,41 @@ class DAFNet(MMSDNet):
             x1, x2, z1_input, z2_input = ins
             eps = eps or [None, None]
             with _Frozen([self.D_Mask, self.D_Image1, self.D_Image2]):
-                # encode
-                s1 = self.Encoders_Anatomy[0](x1, training=training)
-                s2 = self.Encoders_Anatomy[1](x2, training=training)
-                z1, kl1 = self.Enc_Modality(s1, x1, eps=eps[0])
-                z2, kl2 = self.Enc_Modality(s2, x2, eps=eps[1])
+                # encode.  Tensors with several consumers hand every consumer its own alias (ops.Shared): their gradients are then
+                # added by ONE launch in the backward pass instead of pairwise by the autograd engine
+                S = ops.Shared
+                s1_all = self.Encoders_Anatomy[0](x1, training=training)
+                s2_all = self.Encoders_Anatomy[1](x2, training=training)
+                s1, s2 = S(s1_all, 7), S(s2_all, 7)
+                z1, kl1 = self.Enc_Modality(s1.use(), x1, eps=eps[0])
+                z2, kl2 = self.Enc_Modality(s2.use(), x2, eps=eps[1])
+                z1s, z2s = S(z1, 2), S(z2, 2)
                 # segment (BatchNorm batch statistics per call: these stay separate calls)
-                m1 = self.Segmentor(s1, training=training)
-                m2 = self.Segmentor(s2, training=training)
+                m1 = S(self.Segmentor(s1.use(), training=training), 2)
+                m2 = S(self.Segmentor(s2.use(), training=training), 2)
                 # deform and fuse: both directions in one batched call (per-sample component)
-                sd, _ = self.Anatomy_Fuser(ops.cat_batch([s1, s2]), ops.cat_batch([s2, s1]))
-                s1_def, s2_def = ops.split_batch(sd, 2)
-                m2_s1_def = self.Segmentor(s1_def, training=training)
-                m1_s2_def = self.Segmentor(s2_def, training=training)
+                sd, _ = self.Anatomy_Fuser(ops.cat_batch([s1.use(), s2.use()]), ops.cat_batch([s2.use(), s1.use()]))
+                s1_def_all, s2_def_all = ops.split_batch(sd, 2)
+                s1_def, s2_def = S(s1_def_all, 2), S(s2_def_all, 2)
+                m2_s1_def = S(self.Segmentor(s1_def.use(), training=training), 2)
+                m1_s2_def = S(self.Segmentor(s2_def.use(), training=training), 2)
                 # decoder: reconstructions, cross-reconstructions and the Z-regressor's decodings (dafnet.py:336-350) are six
                 # independent per-sample calls -> one batch of 6B
-                ys = self.Decoder(ops.cat_batch([s1, s2, s2_def, s1_def, s1, s2]),
-                                  ops.cat_batch([z1, z2, z1, z2, z1_input, z2_input]))
+                ys = self.Decoder(ops.cat_batch([s1.use(), s2.use(), s2_def.use(), s1_def.use(), s1.use(), s2.use()]),
+                                  ops.cat_batch([z1s.use(), z2s.use(), z1s.use(), z2s.use(), z1_input, z2_input]))
                 y1, y2, y1_s2_def, y2_s1_def, y1_zin, y2_zin = ops.split_batch(ys, 6)
+                y1, y2, y1_s2_def, y2_s1_def = S(y1, 2), S(y2, 2), S(y1_s2_def, 2), S(y2_s1_def, 2)
                 # GANs (frozen discriminators, no batch statistics): one call per discriminator
                 adv_m1, adv_m2, adv_m1_s2_def, adv_m2_s1_def = ops.split_batch(
-                    self.D_Mask(ops.cat_batch([ops.slice_channels(m, 0, nm) for m in (m1, m2, m1_s2_def, m2_s1_def)])), 4)
-                adv_y1, adv_y1_s2_def = ops.split_batch(self.D_Image1(ops.cat_batch([y1, y1_s2_def])), 2)
-                adv_y2, adv_y2_s1_def = ops.split_batch(self.D_Image2(ops.cat_batch([y2, y2_s1_def])), 2)
+                    self.D_Mask(ops.cat_batch([ops.slice_channels(m.use(), 0, nm) for m in (m1, m2, m1_s2_def, m2_s1_def)])), 4)
+                adv_y1, adv_y1_s2_def = ops.split_batch(self.D_Image1(ops.cat_batch([y1.use(), y1_s2_def.use()])), 2)
+                adv_y2, adv_y2_s1_def = ops.split_batch(self.D_Image2(ops.cat_batch([y2.use(), y2_s1_def.use()])), 2)
                 # Z-Regressor: Enc_Modality_mu of the decodings of the sampled z
-                z1_rec = self.Enc_Modality(s1, y1_zin, mu_only=True)
-                z2_rec = self.Enc_Modality(s2, y2_zin, mu_only=True)
+                z1_rec = self.Enc_Modality(s1.use(), y1_zin, mu_only=True)
+                z2_rec = self.Enc_Modality(s2.use(), y2_zin, mu_only=True)
+                m1, m2, m1_s2_def, m2_s1_def = m1.use(), m2.use(), m1_s2_def.use(), m2_s1_def.use()
+                y1, y2, y1_s2_def, y2_s1_def = y1.use(), y2.use(), y1_s2_def.use(), y2_s1_def.use()
+                s1, s2, s1_def, s2_def = s1_all, s2_all, s1_def_all, s2_def_all
             all_outputs = [m1, m2, m1_s2_def, m2_s1_def] if supervised else [m1, m1_s2_def]
             all_outputs += [adv_m1, adv_m2, adv_m1_s2_def, adv_m2_s1_def] + \
                            [y1, y2, y1_s2_def, y2_s1_def] + \

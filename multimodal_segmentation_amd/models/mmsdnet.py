@@ -183,23 +183,29 @@ class MMSDNet(BaseNet):
             assert len(x_list) == M, '%d inputs for %d modalities' % (len(x_list), M)
             eps = eps or [None] * n
             with self._frozen(self.D_Mask):
-                s_list = [self.Encoders_Anatomy[i](x_list[i], training=training) for i in range(M)]
-                z_list = [self.Enc_Modality(s_list[i], x_list[i], eps=eps[i]) for i in range(M)]
-                m_own = [self.Segmentor(s, training=training) for s in s_list]
+                # (tensors with several consumers hand out one alias per consumer, ops.Shared: their gradients are added by one
+                # launch in the backward pass instead of pairwise by the autograd engine)
+                S = ops.Shared
+                s_all = [self.Encoders_Anatomy[i](x_list[i], training=training) for i in range(M)]
+                s_list = [S(s, 3 + 2 * (M - 1)) for s in s_all]      # modality encoder, segmentor, decoder, 2 (M - 1) fuser calls
+                z_list = [self.Enc_Modality(s_list[i].use(), x_list[i], eps=eps[i]) for i in range(M)]
+                m_own = [S(self.Segmentor(s.use(), training=training), 2) for s in s_list]
                 # deform + fuse every ordered pair (mmsdnet.py:120-121,160-161 for the two pairs of two modalities)
                 fused = []
                 for (i, j) in pairs:
-                    fused += self.Anatomy_Fuser(s_list[i], s_list[j])           # [s_i_def, s_i_fused]
-                fused_seg = [self.Segmentor(s, training=training) for s in fused]
+                    fused += self.Anatomy_Fuser(s_list[i].use(), s_list[j].use())           # [s_i_def, s_i_fused]
+                fused = [S(f, 3) for f in fused]                      # segmentor, modality encoder, decoder
+                fused_seg = [S(self.Segmentor(s.use(), training=training), 2) for s in fused]
+                # the frozen discriminator and the decoder have no batch statistics: n calls each -> one batched call
+                adv_m_list = ops.split_batch(self.D_Mask(ops.cat_batch([ops.slice_channels(m.use(), 0, nm) for m in m_own + fused_seg])), n)
+                m_own, fused_seg = [m.use() for m in m_own], [m.use() for m in fused_seg]
                 if supervised:
                     m_list = m_own + fused_seg
                 else:        # masks only for modality 0 (mmsdnet.py:107,116): m_0 and the (i -> 0) pairs
                     m_list = [m_own[0]] + [fused_seg[2 * p + k] for p, (_, j) in enumerate(pairs) if j == 0 for k in range(2)]
-                # the frozen discriminator and the decoder have no batch statistics: n calls each -> one batched call
-                adv_m_list = ops.split_batch(self.D_Mask(ops.cat_batch([ops.slice_channels(m, 0, nm) for m in m_own + fused_seg])), n)
                 # z re-encoded from the deformed / fused anatomy and the TARGET modality's image (mmsdnet.py:127-131)
-                z_pair = [self.Enc_Modality(s, x_list[pairs[q // 2][1]], eps=eps[M + q]) for q, s in enumerate(fused)]
-                rec_x_list = ops.split_batch(self.Decoder(ops.cat_batch(s_list + fused),
+                z_pair = [self.Enc_Modality(s.use(), x_list[pairs[q // 2][1]], eps=eps[M + q]) for q, s in enumerate(fused)]
+                rec_x_list = ops.split_batch(self.Decoder(ops.cat_batch([s.use() for s in s_list + fused]),
                                                           ops.cat_batch([z[0] for z in z_list + z_pair])), n)
                 diverg = [z[1] for z in z_list + z_pair]
             return m_list + adv_m_list + rec_x_list + diverg

@@ -36,8 +36,8 @@ def unet_downsample(m, x, training, downsample=4, norm='batch'):
     l = x
     for i in range(downsample):
         d = conv_block(m, 'd%d' % i, l, training, norm=norm)
-        skips.append(d)
-        l = ops.maxpool2(d)
+        l, skip = ops.maxpool2_skip(d)        # d feeds the pooling and the skip concatenation: one node, gradients added in one pass
+        skips.append(skip)
     return l, skips
 
 

@@ -682,6 +682,42 @@ def maxpool2(x):
     return _MaxPool2.apply(x)
 
 
+class _MaxPool2Skip(torch.autograd.Function):
+    """-> (MaxPooling2D(2)(x), x): a down-path activation of the UNet feeds the pooling AND the skip Concatenate (reference
+    models/unet.py:39-51,69-84).  Handing out the second use from the same node lets the backward pass add the two gradients inside
+    the pooling-gradient kernel (one pass) instead of the autograd engine adding them with a torch kernel afterwards."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        x = _c(x)
+        B, H, W, C = x.shape
+        y = _new((B, H // 2, W // 2, C), x, x.dtype)
+        if _h(x):
+            N.call('mmseg_maxpool2_fwd_t', x, y, B, H, W, C, _h(x))
+        else:
+            N.call('mmseg_maxpool2_fwd', x, y, B, H, W, C)
+        ctx.save_for_backward(x, y)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        if dy is None:
+            return dskip
+        x, y = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dx = _new(x.shape, x, x.dtype)
+        add = _c(dskip) if dskip is not None else None
+        assert add is None or add.dtype == x.dtype, 'the gradient of a tensor is stored like the tensor'
+        N.call('mmseg_maxpool2_bwd_add_t', x, y, _c(dy), add, dx, B, H, W, C, _h(x))
+        return dx
+
+
+def maxpool2_skip(x):
+    """-> (pooled, skip): `skip` is x for its second consumer (see _MaxPool2Skip)"""
+    return _MaxPool2Skip.apply(x)
+
+
 class _Upsample2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -1450,14 +1486,142 @@ def affine_gather(data, rows, mat, order=1):
     return out
 
 
+def _sum_n(gs, like):
+    """sum of 1..n same-shaped tensors in as few launches as possible (8 operands per launch, left to right)"""
+    gs = [_c(g) for g in gs]
+    while len(gs) > 1:
+        grp, rest = gs[:8], gs[8:]
+        out = _new(like.shape, like, grp[0].dtype)
+        assert all(g.dtype == grp[0].dtype and g.shape == grp[0].shape for g in grp)
+        N.call('mmseg_sum_n_t', *(grp + [None] * (8 - len(grp))), len(grp), out, out.numel(), _h(out))
+        gs = [out] + rest
+    return gs[0]
+
+
+class _Share(torch.autograd.Function):
+    """n aliases of x for n consumers.  The autograd engine adds the gradients of a tensor with several consumers pairwise with torch
+    kernels (46 additions per DAFNet generator step; 6 of them chained for the anatomy factor alone); consumers that take their
+    own alias meet again HERE, where one launch adds all of them (mmseg_sum_n_t)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        return _sum_n(gs, gs[0]), None
+
+
+class Shared(object):
+    """`s = Shared(x, n)`; every consumer calls `s.use()` (the n-th use hands out the last alias; more uses raise).  Without a tape
+    (inference) it hands out x itself."""
+
+    def __init__(self, x, n):
+        self.x, self.n, self.i = x, n, 0
+        self.parts = _Share.apply(x, n) if (n > 1 and torch.is_grad_enabled() and x.requires_grad) else None
+
+    def use(self):
+        if self.parts is None:
+            return self.x
+        if self.i >= self.n:
+            raise RuntimeError('Shared tensor declared for %d consumers is used a %d-th time' % (self.n, self.i + 1))
+        self.i += 1
+        return self.parts[self.i - 1]
+
+
+def share(x, n):
+    """-> list of n aliases of x, one per consumer (see _Share)"""
+    sh = Shared(x, n)
+    return [sh.use() for _ in range(n)]
+
+
+def _cat_words(parts, out):
+    """out (contiguous, n * len(part) rows) <- parts stacked on the leading axis; a None part is written as zeros"""
+    n = len(parts)
+    B = out.shape[0] // n
+    words = (out.numel() // n) * out.element_size()
+    assert words % 4 == 0, 'batch concatenation moves 4-byte words'
+    words //= 4
+    for k0 in range(0, n, 8):
+        grp = parts[k0:k0 + 8]
+        N.call('mmseg_cat_words', *(list(grp) + [None] * (8 - len(grp))), len(grp), out[k0 * B:(k0 + len(grp)) * B], words)
+
+
+class _CatBatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *ts):
+        ts = [_c(t) for t in ts]
+        t0 = ts[0]
+        assert all(t.shape == t0.shape and t.dtype == t0.dtype for t in ts), 'cat_batch: equally shaped parts'
+        out = _new((len(ts) * t0.shape[0],) + tuple(t0.shape[1:]), t0, t0.dtype)
+        _cat_words(ts, out)
+        ctx.n, ctx.B = len(ts), t0.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        return tuple(g[i * ctx.B:(i + 1) * ctx.B] for i in range(ctx.n))      # contiguous row blocks: views, nothing is copied
+
+
+class _SplitBatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        x = _c(x)
+        assert x.shape[0] % n == 0
+        B = x.shape[0] // n
+        ctx.meta = (tuple(x.shape), x.dtype, n)
+        return tuple(x[i * B:(i + 1) * B] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        shape, dtype, n = ctx.meta
+        like = next((g for g in gs if g is not None), None)
+        if like is None:
+            return None, None
+        out = torch.empty(shape, dtype=dtype, device=like.device)
+        _cat_words([_c(g) if g is not None else None for g in gs], out)
+        return out, None
+
+
 def cat_batch(tensors):
-    """Stack independent calls of a per-sample component on the batch axis (pure data movement; autograd hands every
-    producer its slice of the gradient).  Components without batch statistics -- discriminators, FiLM / SPADE decoders,
-    the anatomy fuser, inference-mode BatchNorm -- give identical per-sample results, with 1/n of the launches and
-    GEMMs large enough to fill the chip."""
-    return torch.cat([_c(t) for t in tensors], dim=0)
+    """Stack independent calls of a per-sample component on the batch axis (pure data movement in one launch, mmseg_cat_words; the
+    backward pass hands every producer its row block of the gradient as a view).  Components without batch statistics --
+    discriminators, FiLM / SPADE decoders, the anatomy fuser, inference-mode BatchNorm -- give identical per-sample results, with
+    1/n of the launches and GEMMs large enough to fill the chip."""
+    tensors = list(tensors)
+    if len(tensors) == 1:
+        return tensors[0]
+    return _CatBatch.apply(*tensors)
 
 
 def split_batch(t, n):
-    """inverse of cat_batch for n equal parts"""
-    return list(torch.chunk(t, n, dim=0))
+    """inverse of cat_batch for n equal parts (views; their gradients are gathered into one tensor by one launch)"""
+    if n == 1:
+        return [t]
+    return list(_SplitBatch.apply(t, n))
+
+
+def gather_rows(src, idx):
+    """src[idx] along the leading axis (idx: int64 device tensor): sampling a fake pool (utils/data_utils.py sample of the reference)"""
+    src = _c(src)
+    rows = idx.numel()
+    out = _new((rows,) + tuple(src.shape[1:]), src, src.dtype)
+    row_bytes = (src.numel() // max(src.shape[0], 1)) * src.element_size()
+    assert row_bytes % 4 == 0
+    N.call('mmseg_gather_rows', src, idx, out, rows, row_bytes // 4, src.shape[0])
+    return out
+
+
+def add_residual(m):
+    """[..., C] masks -> [..., C + 1]: background channel = 1 unless some mask equals 1 exactly (base_executor.py:83-87)"""
+    m = _c(m)
+    C = m.shape[-1]
+    out = _new(tuple(m.shape[:-1]) + (C + 1,), m)
+    N.call('mmseg_add_residual', m, out, m.numel() // C, C)
+    return out

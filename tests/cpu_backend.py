@@ -243,6 +243,42 @@ def maxpool2_bwd(x, y, dy, dx, B, H, W, C):
     dx.copy_(g); return 0
 
 
+def maxpool2_bwd_add_t(x, y, dy, add, dx, B, H, W, C, h):
+    maxpool2_bwd(x, y, dy, dx, B, H, W, C)
+    if add is not None:
+        dx.add_(add.reshape(dx.shape))
+    return 0
+
+
+def sum_n_t(p0, p1, p2, p3, p4, p5, p6, p7, n, out, numel, h):
+    ps = [p0, p1, p2, p3, p4, p5, p6, p7][:n]
+    acc = ps[0].reshape(-1).float().clone()
+    for q in ps[1:]:
+        acc += q.reshape(-1).float()
+    out.copy_(acc.reshape(out.shape).to(out.dtype)); return 0
+
+
+def cat_words(p0, p1, p2, p3, p4, p5, p6, p7, n, out, words):
+    ps = [p0, p1, p2, p3, p4, p5, p6, p7][:n]
+    B = out.shape[0] // n
+    for k, q in enumerate(ps):
+        if q is None:
+            out[k * B:(k + 1) * B].zero_()
+        else:
+            out[k * B:(k + 1) * B].copy_(q.reshape(out[k * B:(k + 1) * B].shape))
+    return 0
+
+
+def gather_rows(src, idx, out, rows, words, src_rows):
+    out.copy_(src.index_select(0, idx.long()).reshape(out.shape)); return 0
+
+
+def add_residual(msk, out, M, C):
+    m = msk.reshape(M, C)
+    res = 1.0 - (m == 1).any(-1, keepdim=True).to(m.dtype)
+    out.copy_(torch.cat([m, res], -1).reshape(out.shape)); return 0
+
+
 def upsample2_bwd(dy, dx, B, H, W, C):
     d = dy.reshape(B, H, 2, W, 2, C).sum((2, 4))
     dx.copy_(d); return 0

@@ -186,6 +186,92 @@ def test_spade_gamma_beta_as_one_convolution(B, H, W, Cin, f, alpha, device):
     check(f_prod, f_ref, [a, x, wg, bg, wb, bb], device, param_idx=(2, 3, 4, 5))
 
 
+@pytest.mark.parametrize('n', [2, 7, 15])
+def test_shared_tensor_gradients_are_summed_by_the_library(n, device):
+    """ops.Shared / ops.share: n consumers of one tensor, each through its own alias -> the gradient is the sum of the n cotangents
+    (one mmseg_sum_n_t launch per 8 operands), no addition is left to the autograd engine"""
+    x = rnd(2, 6, 5, 8, seed=3).to(device).requires_grad_(True)
+    ws = [rnd(2, 6, 5, 8, seed=10 + i) for i in range(n)]
+    sh = P.Shared(x, n)
+    total = None
+    for i in range(n):
+        a = sh.use()
+        assert a.data_ptr() == x.data_ptr()
+        t = P.axpby(a, a, 0.5, 0.5)      # a library op without a tape entry: keep the alias itself as the graph output
+        del t
+    with pytest.raises(RuntimeError):
+        sh.use()
+    outs = list(P.share(x, n))
+    torch.autograd.backward(outs, [w.to(device) for w in ws])
+    _close(x.grad, sum(w.double() for w in ws), 'shared grad')
+    # unused aliases contribute nothing (and are not materialised as zeros)
+    x.grad = None
+    outs = list(P.share(x, n))
+    torch.autograd.backward(outs[:1], [ws[0].to(device)])
+    _close(x.grad, ws[0].double(), 'one consumer')
+
+
+@pytest.mark.parametrize('n,shape', [(2, (3, 4, 4, 8)), (6, (2, 8)), (15, (1, 3, 3, 4))])
+def test_cat_and_split_batch(n, shape, device):
+    """ops.cat_batch / ops.split_batch (mmseg_cat_words): values, and gradients through both directions incl. unused splits"""
+    parts = [rnd(*shape, seed=20 + i) for i in range(n)]
+    xs = [t.clone().to(device).requires_grad_(True) for t in parts]
+    y = P.cat_batch(xs)
+    _close(y, torch.cat(parts, 0).double(), 'cat')
+    cot = rnd(*y.shape, seed=5)
+    y.backward(cot.to(device))
+    for i, x in enumerate(xs):
+        _close(x.grad, cot[i * shape[0]:(i + 1) * shape[0]].double(), 'cat grad %d' % i)
+    big = rnd(n * shape[0], *shape[1:], seed=6).to(device).requires_grad_(True)
+    sp = P.split_batch(big, n)
+    for i, t in enumerate(sp):
+        _close(t, big.detach().cpu()[i * shape[0]:(i + 1) * shape[0]].double(), 'split %d' % i)
+    use = [i for i in range(n) if i % 2 == 0]
+    cots = {i: rnd(*shape, seed=40 + i) for i in use}
+    torch.autograd.backward([sp[i] for i in use], [cots[i].to(device) for i in use])
+    want = torch.zeros(n * shape[0], *shape[1:], dtype=torch.float64)
+    for i in use:
+        want[i * shape[0]:(i + 1) * shape[0]] = cots[i].double()
+    _close(big.grad, want, 'split grad')
+
+
+def test_maxpool_with_skip(device):
+    """ops.maxpool2_skip: pooled output + the skip alias; the two gradients meet in ONE pass (mmseg_maxpool2_bwd_add_t)"""
+    x0 = rnd(2, 8, 6, 8, seed=2)
+    x = x0.clone().to(device).requires_grad_(True)
+    y, skip = P.maxpool2_skip(x)
+    xr = x0.clone().double().requires_grad_(True)
+    yr = O.maxpool2(xr)
+    _close(y, yr, 'pooled')
+    assert skip.data_ptr() == x.data_ptr()
+    gy, gs = rnd(*yr.shape, seed=3), rnd(*x0.shape, seed=4)
+    torch.autograd.backward([y, skip], [gy.to(device), gs.to(device)])
+    torch.autograd.backward([yr, xr * 1.0], [gy.double(), gs.double()])
+    _close(x.grad, xr.grad, 'pool + skip grad')
+    x.grad = None
+    y, skip = P.maxpool2_skip(x)
+    y.backward(gy.to(device))                  # skip unused
+    xr.grad = None
+    O.maxpool2(xr).backward(gy.double())
+    _close(x.grad, xr.grad, 'pool grad only')
+    x.grad = None
+    y, skip = P.maxpool2_skip(x)
+    skip.backward(gs.to(device))               # pooling unused
+    _close(x.grad, gs.double(), 'skip grad only')
+
+
+def test_gather_rows_and_add_residual(device):
+    pool = rnd(12, 4, 4, 3, seed=1).to(device)
+    idx = torch.tensor([5, 0, 11, 5, 7], dtype=torch.int64).to(device)
+    got = P.gather_rows(pool, idx)
+    assert torch.equal(got.cpu(), pool.cpu().index_select(0, idx.cpu()))
+    m = (torch.rand(3, 5, 5, 4, generator=torch.Generator().manual_seed(3)) > 0.8).float()
+    m[0, 0, 0] = torch.tensor([0.5, 0.999, 0., 0.])      # fractional edge values count as background
+    got = P.add_residual(m.to(device)).cpu()
+    res = 1.0 - (m == 1).any(-1, keepdim=True).float()
+    assert torch.equal(got, torch.cat([m, res], -1))
+
+
 def test_anonymous_pair_operands_are_never_cached(device):
     """regression (round-3 driver run): ops.conv2d_pair with wkey=None cached the concatenated gamma|beta operands under the ADDRESS of
     the first kernel.  Free that kernel, allocate a DIFFERENT one of the same byte size (the caching allocator hands out the same block)
