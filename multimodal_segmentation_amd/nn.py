@@ -92,13 +92,14 @@ _serial = itertools.count(1)      # uids of models and parameters: cache keys th
 
 
 class Param(object):
-    __slots__ = ('name', 'shape', 'init', 'trainable', 'data', 'grad', 'owner', 'offset', 'uid')
+    __slots__ = ('name', 'shape', 'init', 'trainable', 'data', 'grad', 'owner', 'offset', 'uid', 'seg')
 
     def __init__(self, name, shape, init, trainable=True):
         self.name, self.shape, self.init, self.trainable = name, tuple(shape), init, trainable
         self.uid = next(_serial)
         self.data = self.grad = self.owner = None
         self.offset = 0
+        self.seg = 0           # segment of the owner's gradient arena this parameter lies in (Model.grad_segments)
 
     @property
     def numel(self):
@@ -109,8 +110,8 @@ class Param(object):
         if not (self.trainable and self.owner.trainable and torch.is_grad_enabled()):
             return None
         tr = dp.current_tracker()
-        if tr is not None:                 # data parallel: count the launches that will accumulate into this arena
-            tr.register(self.owner)
+        if tr is not None:                 # data parallel: count the launches that will accumulate into this arena segment
+            tr.register(self.owner, self.seg)
         return self.grad
 
 
@@ -125,6 +126,7 @@ class Model(object):
         self.trainable = True
         self.params = OrderedDict()
         self.arena = self.grad_arena = self.state_arena = None
+        self.grad_segments = [(0, 0)]      # contiguous [start, end) ranges of grad_arena that are all-reduced separately (parallel/dp.py)
         self.input_shape = self.output_shape = None
         self.shared = []           # other Models whose weights are part of this one (shared layers)
         self.precision = None      # (compute_dtype, 16-bit activation storage) of the model wrapper that built it; None: inherit
@@ -145,6 +147,19 @@ class Model(object):
                 p.offset, off_t = off_t, off_t + n
             else:
                 p.offset, off_s = off_s, off_s + n
+        # data-parallel segments: cut at layer boundaries (a '/kernel' that opens a new layer) once a segment holds >= SEGMENT_FLOATS
+        segs, start, cur_layer = [], 0, None
+        for p in self.params.values():
+            if not p.trainable:
+                continue
+            layer = p.name.split('/')[0]
+            if layer != cur_layer and p.name.endswith('/kernel') and p.offset - start >= dp.SEGMENT_FLOATS:
+                segs.append((start, p.offset))
+                start = p.offset
+            cur_layer = layer
+            p.seg = len(segs)
+        segs.append((start, max(off_t, 4)))
+        self.grad_segments = segs
         host_t = np.zeros(max(off_t, 4), np.float32)
         host_s = np.zeros(max(off_s, 4), np.float32)
         for p in self.params.values():
@@ -159,6 +174,7 @@ class Model(object):
                 p.data = self.arena[p.offset:p.offset + p.numel].view(p.shape)
                 p.grad = self.grad_arena[p.offset:p.offset + p.numel].view(p.shape)
                 p.grad._owner = self           # lets the autograd Functions report 'gradient queued' to the DP tracker
+                p.grad._seg = p.seg
             else:
                 p.data = self.state_arena[p.offset:p.offset + p.numel].view(p.shape)
         self.device = device

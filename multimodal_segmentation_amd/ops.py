@@ -349,7 +349,7 @@ def _grad_done(*grads):
     for t in grads:
         owner = getattr(t, '_owner', None) if t is not None else None
         if owner is not None:
-            tr.done(owner)
+            tr.done(owner, getattr(t, '_seg', 0))
 
 
 def _accumulate(dst, src):

@@ -3,8 +3,9 @@
 The path shards by independent slice pairs: every rank holds a full replica of the weights and processes its own
 batch; the only exchanges are
   (i)  an all-reduce (mean) of each trainer's gradient arenas -- flat, 16-byte aligned fp32 buffers
-       (nn.Model.grad_arena), one collective per component model, largest ~119 MB (shared UNet up path) -- OVERLAPPED
-       WITH THE BACKWARD PASS: every kernel launch that accumulates into an arena is counted in the forward pass
+       (nn.Model.grad_arena), one collective per arena SEGMENT (layer-aligned, contiguous ranges of >= SEGMENT_FLOATS
+       floats, nn.Model.grad_segments: the 119 MB arena of the shared UNet up path is six collectives in the order its
+       layers finish in the backward pass, every other component one or two) -- OVERLAPPED WITH THE BACKWARD PASS: every kernel launch that accumulates into an arena is counted in the forward pass
        (GradTracker.register, from nn.Param.g) and un-counted when its backward has been queued (GradTracker.done, from
        the autograd Functions of ops.py); when a model's count returns to zero its arena is final and its all-reduce is
        issued at once (async: RCCL runs it on its own stream behind the kernels queued so far) while the backward pass
@@ -20,6 +21,12 @@ import torch
 import torch.distributed as dist
 
 _state = {'enabled': False}
+
+# A gradient arena is all-reduced in layer-aligned segments of at least this many floats (16 MB): large enough for a ring over xGMI's
+# point-to-point links to run at its bandwidth, small enough that the collectives of a big arena (shared UNet up path: 119 MB, whose
+# last layer -- the bottleneck -- finishes just before the first encoder's down path) start while its other layers are still in the
+# backward pass instead of all at once behind the last of them.
+SEGMENT_FLOATS = 4 * 1024 * 1024
 
 
 def enable(flag=True, force=False):
@@ -62,8 +69,9 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         kw = {'device_id': torch.device('cuda', local_rank)} if (use_gpu and backend == 'nccl') else {}
         dist.init_process_group(backend, **kw)
-    if _state.get('host_group') is None and dist.get_backend() != 'gloo':
-        # a CPU-side group for waits of unbounded length (host_barrier): created collectively, here, by every rank
+    if _state.get('host_group') is None:
+        # a CPU-side group for waits of unbounded length (host_barrier): created collectively, here, by every rank -- also when the
+        # default group is gloo already (CPU runs): its 30-minute default timeout is the kind this group exists to avoid
         import datetime
         _state['host_group'] = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=48))
     if use_gpu:
@@ -94,7 +102,8 @@ def barrier():
 def host_barrier():
     """wait for every rank WITHOUT a GPU collective: rank 0 evaluates the test split alone after training (experiment.py) while the
     other ranks wait here -- a RCCL barrier would hit the process group's 10-minute watchdog on a real-size test pass.  Uses the
-    gloo side group created by init_from_env (48 h timeout); with a gloo default group the ordinary barrier is already host-side."""
+    gloo side group created by init_from_env (48 h timeout, whatever the default backend); process groups set up by hand fall back
+    to the default group's barrier."""
     if not enabled():
         return
     g = _state.get('host_group')
@@ -160,49 +169,69 @@ def current_tracker():
 
 
 class GradTracker(object):
-    """Issues the all-reduce of a model's gradient arena as soon as the last kernel accumulating into it has been queued."""
+    """Issues the all-reduce of a segment of a model's gradient arena as soon as the last kernel accumulating into it has been queued.
+    Everything here happens on the host thread that queues the backward pass, in the order the autograd engine visits the graph --
+    a function of the graph alone, so every rank issues the same collectives in the same order whatever its timing (`order` is kept
+    for the tests that check exactly that: a mismatch would be a RCCL deadlock on hardware)."""
 
     def __init__(self, models, defer=()):
         self.models = list(models)
-        self.pending = {id(m): 0 for m in self.models}
+        self.pending = {}
+        for m in self.models:
+            for sg in range(len(m.grad_segments)):
+                self.pending[(m.uid, sg)] = 0
+        self.by_uid = {m.uid: m for m in self.models}
         self.used = set()
-        self.defer = set(id(m) for m in defer)      # arenas that still receive gradients after backward (regularisers)
+        self.defer = set(m.uid for m in defer)      # arenas that still receive gradients after backward (regularisers)
         self.fired = set()
         self.works = []
+        self.order = []
 
-    def register(self, owner):
-        k = id(owner)
+    def register(self, owner, seg=0):
+        k = (owner.uid, seg)
         if k in self.pending:
             self.pending[k] += 1
             self.used.add(k)
 
-    def done(self, owner):
-        k = id(owner)
+    def done(self, owner, seg=0):
+        k = (owner.uid, seg)
         if k not in self.pending:
             return
         self.pending[k] -= 1
-        if self.pending[k] == 0 and k not in self.defer and k not in self.fired:
-            self._fire(owner)
+        if self.pending[k] == 0 and owner.uid not in self.defer and k not in self.fired:
+            self._fire(owner, seg)
 
-    def _fire(self, m):
-        self.fired.add(id(m))
-        self.works.append((m, dist.all_reduce(m.grad_arena, op=dist.ReduceOp.SUM, async_op=True)))
+    def _fire(self, m, seg):
+        self.fired.add((m.uid, seg))
+        a, b = m.grad_segments[seg]
+        view = m.grad_arena[a:b]
+        self.order.append((m.name, seg))
+        self.works.append((view, dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)))
 
     def finish(self):
-        """reduce whatever has not been reduced yet (in model order: identical on every rank), wait, average"""
+        """reduce whatever has not been reduced yet (in model and segment order: identical on every rank), wait, average"""
         _state['last_overlapped'] = len(self.works)     # collectives issued during the backward pass
         _state['total_overlapped'] = _state.get('total_overlapped', 0) + len(self.works)
         for m in self.models:
-            if id(m) in self.used and id(m) not in self.fired:
-                self._fire(m)
+            for sg in range(len(m.grad_segments)):
+                if (m.uid, sg) in self.used and (m.uid, sg) not in self.fired:
+                    self._fire(m, sg)
         _state['last_collectives'] = len(self.works)
+        _state['last_order'] = list(self.order)
+        import hashlib
+        _state['order_digest'] = hashlib.sha1((_state.get('order_digest', '') + repr(self.order)).encode()).hexdigest()
         _state['total_collectives'] = _state.get('total_collectives', 0) + len(self.works)
         _state['total_steps'] = _state.get('total_steps', 0) + 1
         from .. import ops
         ws = float(dist.get_world_size())
-        for m, w in self.works:
+        for view, w in self.works:
             w.wait()
-            ops.axpby(m.grad_arena, m.grad_arena, 1.0 / ws, 0.0, out=m.grad_arena)
+            ops.axpby(view, view, 1.0 / ws, 0.0, out=view)
+
+
+def n_segments(models):
+    """collectives one trainer step over these models issues (every segment of every arena once)"""
+    return sum(len(m.grad_segments) for m in models)
 
 
 def begin(models, defer=()):
@@ -222,11 +251,13 @@ def finish(tracker):
 
 def counters(reset=False):
     """gradient collectives since the last reset: {'steps': trainer steps, 'collectives': arena all-reduces, 'overlapped': those issued
-    while the backward pass was still being queued} -- the evidence a first multi-GPU run prints beside its throughput"""
+    while the backward pass was still being queued, 'order_digest': a hash chain over the (arena, segment) sequence of every step, equal on
+    all ranks iff they issued the same collectives in the same order} -- the evidence a first multi-GPU run prints beside its throughput"""
     out = {'steps': _state.get('total_steps', 0), 'collectives': _state.get('total_collectives', 0),
-           'overlapped': _state.get('total_overlapped', 0)}
+           'overlapped': _state.get('total_overlapped', 0), 'order_digest': _state.get('order_digest', '')}
     if reset:
         _state['total_steps'] = _state['total_collectives'] = _state['total_overlapped'] = 0
+        _state['order_digest'] = ''
     return out
 
 

@@ -115,7 +115,7 @@ def _worker_body(rank, world, port, q):
                                  [np.zeros(1, np.float32)] * 2 + [d['z1'][sl], d['z2'][sl]],
                                  eps=[d['eps1'][sl], d['eps2'][sl]])
     # every generator arena was all-reduced while the backward pass was still being queued (overlap), none at the end
-    assert dp._state['last_overlapped'] == len(gens) == dp._state['last_collectives'], dp._state
+    assert dp._state['last_overlapped'] == dp.n_segments(gens) == dp._state['last_collectives'], dp._state
     # ---- combined Dice + swapped-argument BCE on a BN-free head: the averaged gradient must be the global-batch gradient ----
     tiny, ttr = _tiny_seg_trainer()
     dp.broadcast_models([tiny])
@@ -139,7 +139,7 @@ def _worker_body(rank, world, port, q):
     ok1, cs = dp.replicas_identical(all_models)
     # different batches per rank (rank-offset data seed), yet identical replicas afterwards; 5 trainer steps, one collective per arena
     full = dict(ok0=ok0, ok1=ok1, steps=cnt['steps'], collectives=cnt['collectives'], overlapped=cnt['overlapped'],
-                finite=all(np.isfinite(float(v)) for k in losses for v in losses[k]), n_gens=len(gens), checksum=cs[:4])
+                finite=all(np.isfinite(float(v)) for k in losses for v in losses[k]), n_gens=dp.n_segments(gens), checksum=cs[:4])
     q.put((rank, dm_after.numpy(), [g.numpy() for g in gathered], float(h.history['loss'][0]), tiny_grad, seg_grad, seg_state, full))
     dist.barrier()
     dist.destroy_process_group()
@@ -220,6 +220,25 @@ def _worker4(rank, world, port, q):
         ex.init_train_data(device_resident=False, slices_per_volume=1)
         ok0, _ = dp.replicas_identical(all_models)
         dp.counters(reset=True)
+        # uneven host timing: the last rank is slow to issue every collective and rank 1 stalls before every trainer step.  The order of
+        # the collectives is decided by the graph walk on the host thread, never by who is ready first (a mismatch = RCCL deadlock)
+        import time
+        gen_order = []
+        fire0, finish0 = dp.GradTracker._fire, dp.GradTracker.finish
+        if rank == world - 1:
+            def slow_fire(self, m, seg):
+                time.sleep(0.01)
+                return fire0(self, m, seg)
+            dp.GradTracker._fire = slow_fire
+
+        def finish_logged(self):
+            if rank == 1:
+                time.sleep(0.05)
+            out = finish0(self)
+            if len(self.order) > 4:
+                gen_order.append(list(self.order))
+            return out
+        dp.GradTracker.finish = finish_logged
         losses = {n: [] for n in ex.get_loss_names()}
         for _ in range(2):
             ex.train_batch(losses)
@@ -227,7 +246,8 @@ def _worker4(rank, world, port, q):
         ok1, cs = dp.replicas_identical(all_models)
         first = float(losses[ex.get_loss_names()[0]][0])
         q.put((rank, dict(ok0=ok0, ok1=ok1, steps=cnt['steps'], collectives=cnt['collectives'], overlapped=cnt['overlapped'],
-                          finite=all(np.isfinite(float(v)) for k in losses for v in losses[k]), n_gens=len(gens), checksum=cs[:4], first=first)))
+                          finite=all(np.isfinite(float(v)) for k in losses for v in losses[k]), n_gens=dp.n_segments(gens), checksum=cs[:4], first=first, digest=cnt['order_digest'],
+                          order=dp._state['last_order'], gen_order=gen_order)))
         dist.barrier()
         dist.destroy_process_group()
     except BaseException as exc:
@@ -258,5 +278,17 @@ def test_dp_gloo_full_iterations_keep_the_replicas_identical(world):
     for _, f in res:
         assert f['ok0'] and f['ok1'] and f['finite'], f
         assert f['steps'] == 10 and f['collectives'] == 2 * (f['n_gens'] + 4) and f['overlapped'] == 2 * f['n_gens'], f
+    # every rank issued the same collectives in the same order (hash chain over all 10 trainer steps), slow ranks included
+    assert len(set(f['digest'] for _, f in res)) == 1 and res[0][1]['digest'], [f['digest'] for _, f in res]
+    go = res[0][1]['gen_order'][0]
+    assert all(f['gen_order'] == res[0][1]['gen_order'] for _, f in res)
+    # the shared up path (119 MB) goes out in several layer-ordered pieces, its last layers (conv_anatomy, u0 ...) first and the
+    # bottleneck last; the second encoder's down path is complete -- and on the wire -- before the shared path's last piece
+    shared = [sg for name, sg in go if name == 'Enc_Anatomy_shared']
+    assert len(shared) >= 4 and shared == sorted(shared, reverse=True), go
+    names = [name for name, _ in go]
+    last_shared = max(i for i, n in enumerate(names) if n == 'Enc_Anatomy_shared')
+    assert any(n.startswith('Enc_Anatomy_') and n != 'Enc_Anatomy_shared' for n in names[:last_shared]), go
+    for _, f in res:
         assert f['checksum'] == res[0][1]['checksum']
     assert len({round(f['first'], 6) for _, f in res}) > 1, 'every rank reported the same first loss: the ranks saw the same batch'

@@ -52,7 +52,7 @@ def _run_steps(force_dp):
                                          [np.zeros(B, np.float32)] * 2 + [d['z1'], d['z2']],
                                          eps=[d['eps1'], d['eps2']])
         if force_dp:     # every generator arena reduced while the backward pass was still being queued
-            assert dp._state['last_overlapped'] == len(gens) == dp._state['last_collectives'], dp._state
+            assert dp._state['last_overlapped'] == dp.n_segments(gens) == dp._state['last_collectives'], dp._state
         out['loss%d' % it] = h.history['loss'][0]
     torch.cuda.synchronize()
     out['gen'] = [m.arena.detach().cpu().numpy().copy() for m in gens]
