@@ -50,6 +50,12 @@ int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const flo
  * (BASELINE configs #3 / #5: reduced-precision compute with fp32 master weights and fp32 gradient all-reduce).
  * mmseg_set_conv_precision returns the previous mode. */
 int mmseg_set_conv_precision(int mode);
+/* Which kernel multiplies 16-bit tensors with channel counts that are multiples of 64 (the UNet / SPADE 3x3 layers of
+ * models/unet.py:94-101, layers/spade.py:26-33 in the reduced-precision configurations): 0 = always the 128-wide register-staged
+ * kernel, 1 (default) = the 256-pixel direct-to-LDS kernel where the launch has enough tiles, 2 = wherever it applies.  Same
+ * 16-bit products and fp32 accumulation, K tiles of another depth: results agree to fp32 rounding.  Returns the previous mode; other
+ * values only query. */
+int mmseg_conv16_mode(int mode);
 int mmseg_get_conv_precision(void);
 /* y = act(conv(x) * oscale[c] + bias[c]): convolution + inference-mode BatchNormalization (+ReLU) in one launch (`predict` of the
  * conv blocks of models/unet.py:94-101 and model_components/segmentor.py:16-22); oscale / bias from mmseg_bn_infer_fold */

@@ -781,7 +781,7 @@ static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
 // M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / 16-bit input of the fast kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
 // 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel,
 // 10 pw_reduce_kernel<LANES, COUT, VPL>, 12 pw_reduce_wgrad_kernel<...> (M tile field = LANES, N tile field = COUT);
-// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN)
+// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv16_kernel
 static int g_last_kernel = 0;
 #define MMSEG_SET_LAST(fam, bm, bn) (g_last_kernel = (fam) * 1000000 + (bm) * 1000 + (bn))
 template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false>
@@ -1061,6 +1061,8 @@ static int smallconv_dispatch(const ConvParams& p, hipStream_t st) {
     return -1;
 }
 
+#include "conv16.hpp"
+
 // the quad-transposed epilogue stores 4 channels per lane: 16-byte (fp32) / 8-byte (16-bit) aligned output rows
 static int quad_epilogue_ok(const ConvParams& p) {
     static const bool on = ab_int("MMSEG_QUAD_EPI", 1) != 0;
@@ -1100,6 +1102,14 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (!fast && (p.io & 3)) return (int)hipErrorInvalidValue;       // only the fast path reads 16-bit input tensors
     if (!fast && p.w == nullptr) return (int)hipErrorInvalidValue;   // the generic kernels read the Keras-layout weights: a caller
                                                                      // that only prepared `wt` must not fall through to them
+    if (fast && g_conv_bf16 != 0) {
+        // 16-bit tensors, channel counts multiples of 64, enough pixels: the large-tile direct-to-LDS kernel (conv16.hpp)
+        const int bn = conv16_tile(p);
+        if (bn) {
+            MMSEG_SET_LAST(14, 256, bn);
+            return g_conv_bf16 == 1 ? launch_conv16_prec<1>(p, bn, st) : launch_conv16_prec<2>(p, bn, st);
+        }
+    }
     if (fast) {
         static const int force_tile = ab_int("MMSEG_FAST_TILE", 0);   // tile A/B measurements
         if (force_tile == 1) return launch_fast<128, 128, 2, 2>(p, st);
@@ -2166,6 +2176,13 @@ __global__ void wprep_parity_all_kernel(const float* __restrict__ w, float* __re
 }
 
 extern "C" {
+// large-tile 16-bit kernel (conv16.hpp): 0 off, 1 where it pays (default), 2 wherever it applies; returns the previous mode
+int mmseg_conv16_mode(int mode) {
+    const int old = g_conv16_mode;
+    if (mode >= 0 && mode <= 2) g_conv16_mode = mode;
+    return old;
+}
+
 
 // Process-wide precision of the fast-path convolutions (forward, data gradient, weight gradient): 0 = fp32 MFMA, 1 = bf16,
 // 2 = fp16 operands with fp32 accumulation (BASELINE configs #3 / #5).  Returns the previous mode.  Not a per-launch argument: the trainers switch it once.

@@ -1,0 +1,297 @@
+// Large-tile implicit-GEMM convolution for 16-bit tensors (bf16 / fp16 operands on v_mfma_f32_32x32x16_*, fp32 accumulation):
+// the reduced-precision configurations of BASELINE.json (#3 DAFNet-SPADE bf16, #5 MMSDNet fp16) -- reference layers
+// models/unet.py:94-101, layers/spade.py:26-33 (Conv2D 3x3 'same' on 64..1024 channels) and their data gradients.
+//
+// Why a second kernel: the 4-wave 128 x 128 kernel of conv.hip stages every tile through VGPRs (global load -> ds_write_b128) and
+// synchronises once per 64-deep K tile with 16 MFMAs per wave in between; with 16-bit MFMAs (32 cycles each instead of 64 x 8) the
+// LDS store path (~79 B/clk/CU for ds_write_b128) plus the LDS reads cost more cycles per K tile than the matrix pipe has work, and
+// the single load stage in flight does not cover an L2 round trip: 0.15-0.23 of the 2.5 PFLOP/s peak (round 3).  Here:
+//   * block tile 256 pixels x 256 / 128 / 64 output channels, K tile 64, 8 waves (4 for the 64-channel tile); a wave owns 128 x 64 or
+//     64 x 64 outputs = 8 or 4 accumulator tiles -> 32 / 16 MFMAs per wave between two barriers, 6 or 4 LDS reads per 8 or 4 MFMAs;
+//   * tiles go global -> LDS directly (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write), one 1 KB piece = 8 rows x 128
+//     bytes per wave-instruction; the LDS image is lane-linear, so the bank swizzle of the fragment reads ((row >> 1) & 7 on the
+//     16-byte chunk index, conflict-free for ds_read_b128) is applied to each lane's SOURCE address; image borders and rows beyond
+//     the tensors use out-of-range buffer offsets, which the hardware turns into zeros in LDS;
+//   * a ring of NS LDS stages filled NS - 1 tiles ahead; one counted `s_waitcnt vmcnt` + one raw s_barrier per K tile: the wait
+//     retires the tile needed NEXT (issued a whole iteration earlier), the youngest tile stays in flight across the barrier;
+//   * XCD-aware block order, tap-fastest K order and 2-D pixel tiles as in conv_fast_body.
+// Hazards.  RAW: a stage is read only after every wave waited for its own pieces of it (vmcnt) and passed the barrier behind that
+// wait.  WAR: a stage is refilled one barrier after the iteration that read it, and that barrier is preceded by lgkmcnt(0).
+#pragma once
+
+template <int BM, int BN, int WM, int WN, int NS, int PREC>
+__device__ __forceinline__ void conv16_body(const ConvParams& p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int KT = 64, ROWB = 128;                        // K tile (elements), bytes per LDS row
+    constexpr int AG = BM / 8 / NW, BG = BN / 8 / NW;         // 8-row pieces per wave and tile: activations, weights
+    constexpr int LPT = AG + BG;                              // LDS-DMA instructions per wave (= per lane) and tile
+    constexpr int STAGE = (BM + BN) * ROWB;                   // bytes per ring stage
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces divide evenly over the waves");
+    static_assert(NS == 2 || NS == 3, "ring depth");
+    static_assert(NS * STAGE <= 160 * 1024, "LDS");
+    typedef typename LowPrec<PREC>::V8 LV8;
+    typedef typename LowPrec<PREC>::T LT;
+
+    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];          // ONE shared object (guide: a second one de-pipelines the loop)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nblk = gridDim.x;
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int lb = xcd_remap(blockIdx.x, nblk);
+    const int ntm = nblk / ntn;
+    const bool w_major = (long)p.K * p.Cout > (long)p.M * (p.C1 + p.C2);      // consecutive ids share the bigger operand (conv_fast_body)
+    const int mt = w_major ? lb % ntm : lb / ntn;
+    const int n0 = (w_major ? lb / ntm : lb % ntn) * BN;
+    constexpr int TH = BM / 16;
+    const bool tile2d = (p.Wo % 16 == 0) && (p.Ho % TH == 0);
+    const int tpr = tile2d ? p.Wo / 16 : 1, tpi = tile2d ? (p.Ho / TH) * tpr : 1;
+    const int t_b = tile2d ? mt / tpi : 0, t_r = tile2d ? mt - t_b * tpi : 0;
+    const int t_y0 = tile2d ? (t_r / tpr) * TH : 0, t_x0 = tile2d ? (t_r % tpr) * 16 : 0;
+    const int m0 = mt * BM;
+    auto row_to_m = [&](int row) -> int {
+        return tile2d ? (t_b * p.Ho + t_y0 + (row >> 4)) * p.Wo + t_x0 + (row & 15) : m0 + row;
+    };
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
+                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.K * p.Cout * 2, 0x00020000);
+
+    // ---- per-lane staging state.  Piece g of a tile = rows 8 g .. 8 g + 7; lane l fills LDS chunk (l & 7) of row 8 g + (l >> 3) with
+    // SOURCE chunk sc = (l & 7) ^ swz(row): the read side looks chunk j up at position j ^ swz(row).  swz(row) = (row >> 1) & 7 =
+    // (4 g + (l >> 4)) & 7, so sc = lx ^ (4 (g & 1)) with lx = (l & 7) ^ (l >> 4).
+    // Per row: a_o1 / a_o2 = BYTE offset of (b, hb, wb, source chunk) in x1 / x2 (x1 with up-sampling: of the low-resolution pixel
+    // (hb >> 1, wb >> 1)), a_msk = validity bit per tap (bit kh * KW + kw; the host keeps KH * KW <= 30) and, with up-sampling, the
+    // parities of hb / wb in bits 30 / 31: (hb + kh) >> 1 = (hb >> 1) + ((hb & 1) + kh) >> 1, so a tap's offset is a_o1 + a small
+    // per-lane delta.  The issue of a tile is then one add and one select per 1 KB piece (the loop is bound by instruction issue, not
+    // by the matrix pipe, if it carries more: measured 8 VALU + 7 SALU per MFMA in the first version of this kernel).
+    const int HoWo = p.Ho * p.Wo;
+    const int lx = (lane & 7) ^ (lane >> 4);
+    int a_o1[AG], a_o2[AG];
+    unsigned a_msk[AG];
+#pragma unroll
+    for (int j = 0; j < AG; ++j) {
+        const int g = wid * AG + j;
+        const int row = 8 * g + (lane >> 3);
+        const int sc16 = 16 * (lx ^ (4 * (g & 1)));
+        const int m = row_to_m(row);
+        a_msk[j] = 0u; a_o1[j] = 0; a_o2[j] = 0;
+        if (m < p.M) {
+            int b, ho, wo;
+            if (tile2d) { b = t_b; ho = t_y0 + (row >> 4); wo = t_x0 + (row & 15); }
+            else { b = m / HoWo; const int r = m - b * HoWo; ho = r / p.Wo; wo = r - ho * p.Wo; }
+            const int hb = ho * p.stride - p.pad_h, wb = wo * p.stride - p.pad_w;
+            unsigned wm_ = 0u, msk = 0u;
+            for (int kw = 0; kw < p.KW; ++kw)
+                if ((unsigned)(wb + kw) < (unsigned)p.W) wm_ |= 1u << kw;
+            for (int kh = 0; kh < p.KH; ++kh)
+                if ((unsigned)(hb + kh) < (unsigned)p.H) msk |= wm_ << (kh * p.KW);
+            if (p.ups) {
+                a_o1[j] = ((b * p.H1 + (hb >> 1)) * p.W1 + (wb >> 1)) * p.C1 * 2 + sc16;
+                msk |= ((unsigned)(hb & 1) << 30) | ((unsigned)(wb & 1) << 31);
+            } else {
+                a_o1[j] = ((b * p.H + hb) * p.W + wb) * p.C1 * 2 + sc16;
+            }
+            a_o2[j] = ((b * p.H + hb) * p.W + wb) * p.C2 * 2 + sc16;
+            a_msk[j] = msk;
+        }
+    }
+    constexpr int FAR = 0x40000000;
+    int b_o[BG];
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+        const int g = wid * BG + j;
+        const int n = n0 + 8 * g + (lane >> 3);
+        b_o[j] = n < p.Cout ? (n * p.K + 8 * (lx ^ (4 * (g & 1)))) * 2 : FAR;
+    }
+    // wave-uniform position of the next K tile to issue: tap (s_kh, s_kw), channel base s_c0, and what follows from them
+    int s_c0 = 0, s_kh = 0, s_kw = 0, s_tap = 0;
+    const int Cin2 = (p.C1 + p.C2) * 2;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue_tile = [&](const int stage, const bool live) {
+        char* base = smem + stage * STAGE + wid * (AG * 1024);
+        char* bbase = smem + stage * STAGE + BM * ROWB + wid * (BG * 1024);
+        const unsigned tbit = live ? 1u << s_tap : 0u;
+        const int b_koff = live ? s_tap * Cin2 + s_c0 * 2 : FAR;
+        if (s_c0 < p.C1) {                                    // the tile lies in x1 (wave-uniform)
+            if (p.ups) {
+#pragma unroll
+                for (int j = 0; j < AG; ++j) {
+                    const int dh = ((int)((a_msk[j] >> 30) & 1u) + s_kh) >> 1, dw = ((int)(a_msk[j] >> 31) + s_kw) >> 1;
+                    const int off = a_o1[j] + ((dh * p.W1 + dw) * p.C1 + s_c0) * 2;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(base + j * 1024), 16, (a_msk[j] & tbit) ? off : BUF_OOB, 0, 0, 0);
+                }
+            } else {
+                const int toff = ((s_kh * p.W + s_kw) * p.C1 + s_c0) * 2;
+#pragma unroll
+                for (int j = 0; j < AG; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(base + j * 1024), 16, (a_msk[j] & tbit) ? a_o1[j] + toff : BUF_OOB, 0, 0, 0);
+            }
+        } else {
+            const int toff = ((s_kh * p.W + s_kw) * p.C2 + (s_c0 - p.C1)) * 2;
+#pragma unroll
+            for (int j = 0; j < AG; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr)(base + j * 1024), 16, (a_msk[j] & tbit) ? a_o2[j] + toff : BUF_OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BG; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(bbase + j * 1024), 16, b_o[j] + b_koff, 0, 0, 0);
+        // taps fastest inside a 64-channel chunk (consecutive tiles re-read the same cache lines, shifted)
+        ++s_tap;
+        if (++s_kw == p.KW) { s_kw = 0; if (++s_kh == p.KH) { s_kh = 0; s_tap = 0; s_c0 += KT; } }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_row = wm * (BM / WM) + li;
+    const int b_col = wn * (BN / WN) + li;
+    auto mma_tile = [&](const int stage) {
+        const char* A = smem + stage * STAGE;
+        const char* Bt = A + BM * ROWB;
+        // k-steps of 16: lane half lh supplies k = 16 q + 8 lh + [0, 8) = chunk 2 q + lh.  The fragments of step q + 1 are requested
+        // before the MFMAs of step q (two register sets with static names): the LDS latency sits under 8 / 4 MFMAs, and the
+        // register budget (acc 128 + 2 x 24) stays inside 256 at two waves per SIMD
+        LV8 a[2][TM], b[2][TN];
+        auto frags = [&](const int set, const int q) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = b_col + j * 32;
+                b[set][j] = *reinterpret_cast<const LV8*>(Bt + row * ROWB + 16 * ((2 * q + lh) ^ ((row >> 1) & 7)));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = a_row + i * 32;
+                a[set][i] = *reinterpret_cast<const LV8*>(A + row * ROWB + 16 * ((2 * q + lh) ^ ((row >> 1) & 7)));
+            }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int q = 0; q < KT / 16; ++q) {
+            if (q + 1 < KT / 16) frags((q + 1) & 1, q + 1);
+            // pin the order: without this hipcc sinks the reads of step q + 1 below the MFMAs of step q (one register set, every
+            // k-step then starts with an exposed LDS round trip -- measured: the matrix pipe idle 65 % of the time with NO loads at all)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = LowPrec<PREC>::mfma(a[q & 1][i], b[q & 1][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int nkt = p.K / KT;
+    // ---- prologue: NS - 1 tiles in flight, the first one landed
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_tile(s, s < nkt);
+    if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    int cur = 0, nxt = NS - 1;                       // stage of tile kt; stage the next issue goes to
+    // The two waves that share a SIMD (w and w + NW / 2) run the two halves of an iteration -- queueing the next tile's loads (address
+    // arithmetic, vector-memory issue) and the MFMAs of the current tile -- in OPPOSITE order, so that one of them feeds the matrix
+    // pipe while the other computes addresses; both orders are legal between the same two barriers (the refilled stage was read one
+    // iteration ago, the stage being read is complete) and leave the same loads outstanding at the counted wait.
+    const bool mma_first = NW >= 8 && wid >= NW / 2;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // (tiles beyond K: out-of-range offsets = zeros, no traffic; the outstanding-load count stays exact)
+#ifdef MMSEG_AB
+        const int abl = p.transposed;        // measurement builds: 1 = no loads in the loop, 2 = no MFMAs / fragment reads (results are wrong)
+        if (!mma_first && abl != 1) issue_tile(nxt, kt + NS - 1 < nkt);
+        if (abl != 2) mma_tile(cur);
+        if (mma_first && abl != 1) issue_tile(nxt, kt + NS - 1 < nkt);
+#else
+        if (!mma_first) issue_tile(nxt, kt + NS - 1 < nkt);
+        mma_tile(cur);
+        if (mma_first) issue_tile(nxt, kt + NS - 1 < nkt);
+#endif
+        // tile kt + 1 has landed for this wave once all but the youngest LPT * (NS - 2) loads are done; the barrier makes that true of
+        // every wave's pieces and tells everybody that stage `cur` has been read (it is refilled by the next issue)
+        if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (zero-fill tiles issued past the end)
+
+    // ---- epilogue: conv_fast_body's quad-transposed stores (a lane ends up with 4 consecutive channels of one row), with the row
+    // arithmetic written out as the affine map it is -- m(i, g) = mb + i * si + (g >> 1) * sg + 8 (g & 1) for accumulator tile row
+    // i and register group g, both for the 2-D pixel tiles and for raster rows -- so that nothing but `acc` is live across it (the
+    // generic form made the compiler precompute every row of the 8 tiles and park the accumulators in scratch).  The launcher only
+    // sends launches without an output mapping and with aligned outputs here.
+    {
+        const int tq = lane & 3;
+        const int rb = wm * (BM / WM) + 4 * lh + tq;
+        const int mb = tile2d ? (t_b * p.Ho + t_y0 + (rb >> 4)) * p.Wo + t_x0 + (rb & 15) : m0 + rb;
+        const int si = tile2d ? 2 * p.Wo : 32, sg = tile2d ? p.Wo : 16;
+        const int c1 = p.y2 == nullptr ? p.Cout : p.nsplit1, c2 = p.Cout - c1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + li;
+            const bool nok = n < p.Cout;                 // uniform inside a quad (Cout % 4 == 0)
+            const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+            const float sv = (nok && p.oscale) ? p.oscale[n] : 1.f;
+            const int nq = n - tq;
+            const bool first = nq < c1;
+            char* const obase = reinterpret_cast<char*>(first ? (void*)p.y : (void*)p.y2);
+            const int ocol = first ? nq : nq - c1, ocn = first ? c1 : c2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = act_apply(acc[i][j][4 * g + e] * sv + bv, p.act, p.alpha);
+                    quad_transpose4(a, tq);
+                    const int m = mb + i * si + (g >> 1) * sg + 8 * (g & 1);
+                    if (!nok || m >= p.M) continue;
+#ifdef MMSEG_AB
+                    if (p.transposed == 3 && a[0] != 12345.678f) continue;       // measurement builds: no output stores
+#endif
+                    store4_out(obase, (size_t)m * ocn + ocol, a, p.io);
+                }
+            }
+        }
+    }
+}
+
+// (the body lives in a __device__ function: the host pass must be able to instantiate the __global__ stub without the gfx950 builtins)
+template <int BM, int BN, int WM, int WN, int NS, int PREC>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void conv16_kernel(ConvParams p) {
+    conv16_body<BM, BN, WM, WN, NS, PREC>(p);
+}
+
+// 0: never use this kernel; 1 (default): where it pays; 2: wherever it applies (tests put small problems on it) -- mmseg_conv16_mode
+static int g_conv16_mode = 1;
+// tile choice.  0 = leave the layer to conv_fast_kernel (too few 256-pixel tiles to fill the chip, or K tiles that straddle tensors)
+static int conv16_tile(const ConvParams& p) {
+    if (g_conv16_mode == 0) return 0;
+    if (!(p.io & 1) || (p.C2 && !(p.io & 2)) || p.C1 % 64 || p.C2 % 64 || p.Cout % 8 || p.KH * p.KW > 30) return 0;
+    const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
+    if (omap || !p.qepi || (p.y2 != nullptr && p.nsplit1 % 4)) return 0;      // (what the lean epilogue does not handle)
+    static const int force = ab_int("MMSEG_CONV16", -1);      // measurement builds: 0 off, 64 / 128 / 256 force a tile
+    if (force == 0) return 0;
+    const long mt = (p.M + 255) / 256;
+    int bn = p.Cout > 128 ? 256 : (p.Cout > 64 ? 128 : 64);
+    if (force > 0) bn = force;
+    if (force < 0 && g_conv16_mode != 2 && mt * ((p.Cout + bn - 1) / bn) < 192) return 0;       // fewer than 3/4 of a wave of blocks on 256 CUs
+    return bn;
+}
+template <int PREC>
+static int launch_conv16_prec(const ConvParams& p_, int bn, hipStream_t st) {
+    ConvParams p = p_;
+    p.transposed = ab_int("MMSEG_CONV16_ABL", 0);       // (always 0 on this path; measurement builds: ablation code)
+    const int ntm = (p.M + 255) / 256;
+    if (bn == 256) hipLaunchKernelGGL((conv16_kernel<256, 256, 2, 4, 2, PREC>), dim3(ntm * ((p.Cout + 255) / 256)), dim3(512), 0, st, p);
+    else if (bn == 128) hipLaunchKernelGGL((conv16_kernel<256, 128, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv16_kernel<256, 64, 4, 1, 3, PREC>), dim3(ntm * ((p.Cout + 63) / 64)), dim3(256), 0, st, p);
+    return MMSEG_CHECK_LAUNCH();
+}

@@ -60,6 +60,10 @@ def get_conv_precision():
     return _precision[0]
 
 
+def conv16_mode(mode):
+    return 1
+
+
 def conv2d_parity_taps(K, stride, p):
     return (K - p + stride - 1) // stride if p < K else 0
 

@@ -330,3 +330,87 @@ def test_generator_step_with_16bit_trunk_storage_close_to_fp32_storage(dt, decod
     worst.sort(reverse=True)
     print('worst downstream gradient rel-L2 (16-bit vs fp32 storage):', worst[:6])
     assert worst[0][0] <= (0.5 if decoder == 'spade' else 0.15), worst[:6]
+
+
+@pytest.mark.parametrize('B,H,W,C1,C2,Cout,k,ups,act', [
+    (2, 32, 32, 64, 0, 64, 3, 0, 1),        # 64-wide tile, 2-D pixel tiles
+    (1, 32, 48, 128, 0, 128, 3, 0, 0),      # 128-wide tile
+    (1, 16, 16, 128, 0, 256, 3, 0, 1),      # 256-wide tile, one pixel tile
+    (3, 12, 10, 64, 0, 192, 3, 0, 2),       # raster rows, M = 360 (partial second tile), Cout between tile widths
+    (2, 16, 16, 128, 0, 64, 3, 1, 0),       # nearest x2 up-sampling folded into the gather
+    (1, 32, 32, 64, 64, 128, 3, 0, 1),      # two inputs (skip concatenation): K tiles walk x1, then x2
+    (2, 16, 16, 192, 0, 320, 1, 0, 0),      # 1x1, Cout not a multiple of the tile
+    (1, 20, 20, 64, 0, 72, 5, 0, 0),        # 5x5 taps, Cout = 72
+])
+def test_large_tile_16bit_kernel_equals_the_register_staged_kernel(B, H, W, C1, C2, Cout, k, ups, act, mode):
+    """conv16.hpp (256-pixel tiles, buffer_load ... lds, ring of LDS stages) forced onto small problems (mmseg_conv16_mode 2) against
+    conv_fast_kernel (mode 0): the same 16-bit operands on the same MFMA, sums associated differently -> equal to fp32 rounding;
+    and against the fp64 oracle on the rounded operands."""
+    from oracle import ops as O
+    H1, W1 = (H // 2, W // 2) if ups else (H, W)
+    x1 = rnd(B, H1, W1, C1, seed=1).to(mode).to(DEV)
+    x2 = rnd(B, H, W, C2, seed=2).to(mode).to(DEV) if C2 else None
+    Cin = C1 + C2
+    w = (rnd(k, k, Cin, Cout, seed=3) * (2.0 / (k * k * Cin)) ** 0.5).to(DEV)
+    b = rnd(Cout, seed=4).to(DEV)
+    wp = torch.empty(w.numel(), device=DEV)
+    N.call('mmseg_conv2d_wprep', w, wp, k, k, Cin, Cout, 0)
+    p = k // 2
+    io_in = 1 | (2 if C2 else 0)
+    prev = N.call('mmseg_conv16_mode', 0)
+    try:
+        outs = {}
+        for m16 in (0, 2):
+            N.call('mmseg_conv16_mode', m16)
+            for out16 in (False, True):
+                y = torch.full((B, H, W, Cout), float('nan'), device=DEV, dtype=mode if out16 else torch.float32)
+                N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, W, C1, C2, H, W, Cout, k, k, 1, p, p, ups, 0, act, 0.2, 0,
+                       io_in | (4 if out16 else 0))
+                outs[(m16, out16)] = y
+                fam = N.call('mmseg_conv2d_last_kernel') // 1000000
+                assert fam == (14 if m16 == 2 else 1), 'launch went to kernel family %d' % fam
+        # same operands, same MFMA; the K tiles are 64 channels deep here and 32 or 64 in the other kernel (its choice depends on the
+        # tile): the fp32 sums differ by their association only
+        scale = float(outs[(0, False)].abs().max())
+        assert not torch.isnan(outs[(2, False)]).any() and not torch.isnan(outs[(2, True)].float()).any()
+        assert float((outs[(0, False)] - outs[(2, False)]).abs().max()) <= 1e-5 * scale
+        assert float((outs[(0, True)].float() - outs[(2, True)].float()).abs().max()) <= 2.0 ** -7 * scale
+        assert torch.equal(outs[(2, True)], outs[(2, False)].to(mode)), 'a 16-bit output is the rounding of the fp32 output'
+    finally:
+        N.call('mmseg_conv16_mode', prev)
+    # oracle on the operands as the MFMA sees them (16-bit inputs are exact; the weight image is rounded to the 16-bit type)
+    a = x1.float().cpu().double()
+    if ups:
+        a = O.upsample2(a)
+    if C2:
+        a = torch.cat([a, x2.float().cpu().double()], -1)
+    ref = O.conv2d(a, w.to(mode).float().cpu().double(), b.cpu().double())
+    ref = torch.relu(ref) if act == 1 else (O.leaky_relu(ref, 0.2) if act == 2 else ref)
+    err = float((outs[(2, False)].cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 4e-4, err
+
+
+def test_large_tile_16bit_kernel_split_output_and_scale(mode):
+    """the two-output epilogue (data gradient of a convolution over concatenated inputs: channels [0, n1) -> y, the rest -> y2) and the
+    per-channel scale of the BatchNorm-folded inference convolution, large-tile kernel vs register-staged kernel"""
+    B, H, Cin, C1o, C2o = 2, 16, 128, 64, 64
+    x = rnd(B, H, H, Cin, seed=1).to(mode).to(DEV)
+    w = (rnd(3, 3, Cin, C1o + C2o, seed=3) * 0.03).to(DEV)
+    wp = torch.empty(w.numel(), device=DEV)
+    N.call('mmseg_conv2d_wprep', w, wp, 3, 3, Cin, C1o + C2o, 0)
+    scale, shift = (rnd(C1o + C2o, seed=5) * 0.1 + 1).to(DEV), rnd(C1o + C2o, seed=6).to(DEV)
+    prev = N.call('mmseg_conv16_mode', 0)
+    try:
+        res = {}
+        for m16 in (0, 2):
+            N.call('mmseg_conv16_mode', m16)
+            y1 = torch.empty(B, H, H, C1o, device=DEV, dtype=mode)
+            y2 = torch.empty(B, H, H, C2o, device=DEV, dtype=mode)
+            N.call('mmseg_conv2d_fwd_t', x, None, w, wp, None, y1, y2, B, H, H, Cin, 0, H, H, C1o + C2o, 3, 3, 1, 1, 1, 0, 0, 0, 0.0, C1o, 1 | 4)
+            ys = torch.empty(B, H, H, C1o + C2o, device=DEV, dtype=mode)
+            N.call('mmseg_conv2d_fwd_scaled_t', x, None, w, wp, shift, scale, ys, B, H, H, Cin, 0, H, H, C1o + C2o, 3, 3, 1, 1, 1, 0, 1, 0.0, 1 | 4)
+            res[m16] = (y1, y2, ys)
+        for a, c in zip(res[0], res[2]):
+            assert float((a.float() - c.float()).abs().max()) <= 2.0 ** -7 * float(a.float().abs().max())
+    finally:
+        N.call('mmseg_conv16_mode', prev)
