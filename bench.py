@@ -294,6 +294,9 @@ def main():
                     help='bf16: bf16 MFMA operands (fp32 accumulation, fp32 tensors in HBM, fp32 weight gradients) -- configs #3/#5')
     ap.add_argument('--act16', action='store_true',
                     help='with --dtype bf16 | f16: the activations / gradients of the MFMA trunk live in HBM in the 16-bit type (conf.act_storage = half)')
+    ap.add_argument('--conv16', type=int, default=1, choices=[0, 1, 2],
+                    help='16-bit runs: which kernel multiplies the 64-channel-multiple layers (mmseg_conv16_mode): 0 register-staged 128-wide '
+                         'kernel only, 1 (default) the 256-pixel direct-to-LDS kernels where they pay, 2 wherever they apply')
     ap.add_argument('--graphs', action='store_true',
                     help='conf.hip_graphs: every trainer step is recorded into a hipGraph after two eager steps and replayed (single GPU)')
     ap.add_argument('--multi-stream', action='store_true',
@@ -361,6 +364,9 @@ def main():
     cfg['l_mix'] = args.l_mix
     cfg['n_pairs'] = 1
     cfg['compute_dtype'] = {'f32': 'fp32', 'bf16': 'bf16', 'f16': 'fp16'}[args.dtype]
+    if args.conv16 != 1:
+        from multimodal_segmentation_amd import _native as _N
+        _N.call('mmseg_conv16_mode', args.conv16)
     if args.act16:
         if args.dtype == 'f32':
             raise SystemExit('--act16 needs --dtype bf16 or f16')
@@ -516,7 +522,7 @@ def main():
                                           args.decoder, H, args.batch, args.dtype + ('-act16' if args.act16 else ''), args.l_mix)
         traffic = {}
         tname = 'r02_conv_traffic.json'
-        for cand in ('r03_conv_traffic.json', 'r02_conv_traffic.json'):      # the latest round's PMC passes that cover this workload
+        for cand in ('r04_conv_traffic.json', 'r03_conv_traffic.json', 'r02_conv_traffic.json'):      # the latest round's PMC passes that cover this workload
             tpath = os.path.join(ROOT, 'profiles', cand)
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get('workloads', {}).get(wkey, {})
@@ -593,12 +599,25 @@ def main():
             line['multi_stream'] = multi
         # share of the timed window with a kernel running, from the rocprofv3 kernel trace of THIS command committed under profiles/
         # (tools/gpu_busy.py; like `traffic` it cannot be measured from inside the process without timing every launch)
-        bpath = os.path.join(ROOT, 'profiles', 'r03_gpu_busy_bench_%s_%s_%d_bs%d.txt' % (args.model, args.decoder, H, args.batch))
-        if args.dtype == 'f32' and args.l_mix == 1.0 and not args.graphs and not args.multi_stream and os.path.exists(bpath):
-            import re
-            m = re.search(r'= ([0-9.]+) % GPU-busy', open(bpath).read())
-            if m:
-                line['gpu_busy_frac'] = {'value': float(m.group(1)) / 100.0, 'source': os.path.relpath(bpath, ROOT) + ' (rocprofv3 --kernel-trace of this command)'}
+        # Numbers that are NOT measured by this run but read from rocprofv3 summaries committed under profiles/ (a kernel trace / PMC
+        # passes of this same command, taken by the builder): kept apart from the live measurements under one key, with their files
+        # (advisor, round 3).  `roofline.traffic` is the one such number the line's contract places inside `roofline`: its file is
+        # named in `roofline.traffic_source` and repeated here.
+        committed = {}
+        for rnd in ('r04', 'r03'):
+            bpath = os.path.join(ROOT, 'profiles', '%s_gpu_busy_bench_%s_%s_%d_bs%d.txt' % (rnd, args.model, args.decoder, H, args.batch))
+            if args.dtype == 'f32' and args.l_mix == 1.0 and not args.graphs and not args.multi_stream and os.path.exists(bpath):
+                import re
+                m = re.search(r'= ([0-9.]+) % GPU-busy', open(bpath).read())
+                if m:
+                    committed['gpu_busy_frac'] = {'value': float(m.group(1)) / 100.0, 'source': os.path.relpath(bpath, ROOT)}
+                    break
+        if line.get('roofline', {}).get('traffic'):
+            committed['hbm_traffic_per_launch'] = {'source': 'profiles/%s[%s]' % (tname, wkey),
+                                                   'note': 'rocprofv3 --pmc FETCH_SIZE (x 2 on gfx950) and WRITE_SIZE passes, tools/pmc_traffic.py'}
+        if committed:
+            committed['note'] = 'from committed profiles of this command, not measured in this run'
+            line['from_committed_profile'] = committed
         if world == 1 and not args.no_cpu_baseline and args.model == 'dafnet':
             _progress('cpu baseline (oracle, bounded sample)')
             line['cpu_baseline'] = cpu_baseline(H, args.decoder, args.batch)

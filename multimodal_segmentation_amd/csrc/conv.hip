@@ -781,7 +781,7 @@ static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
 // M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / 16-bit input of the fast kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
 // 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel,
 // 10 pw_reduce_kernel<LANES, COUT, VPL>, 12 pw_reduce_wgrad_kernel<...> (M tile field = LANES, N tile field = COUT);
-// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv16_kernel
+// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv16_kernel, 15 conv16h_kernel
 static int g_last_kernel = 0;
 #define MMSEG_SET_LAST(fam, bm, bn) (g_last_kernel = (fam) * 1000000 + (bm) * 1000 + (bn))
 template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false>
@@ -1105,6 +1105,11 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     if (fast && g_conv_bf16 != 0) {
         // 16-bit tensors, channel counts multiples of 64, enough pixels: the large-tile direct-to-LDS kernel (conv16.hpp)
         const int bn = conv16_tile(p);
+        const int bnh = bn ? conv16h_tile(p) : 0;            // 3x3 'same': the activation patch stays in LDS across the nine taps
+        if (bnh) {
+            MMSEG_SET_LAST(15, 256, bnh);
+            return g_conv_bf16 == 1 ? launch_conv16h_prec<1>(p, bnh, st) : launch_conv16h_prec<2>(p, bnh, st);
+        }
         if (bn) {
             MMSEG_SET_LAST(14, 256, bn);
             return g_conv_bf16 == 1 ? launch_conv16_prec<1>(p, bn, st) : launch_conv16_prec<2>(p, bn, st);
@@ -2479,6 +2484,11 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
         const bool one = KH == 1 && stride == 1 && pad_h == 0 && pad_w == 0;
         long cap = wgrad_splits(p.M, p.K, Cout);                 // slabs the caller's workspace holds
         if (cap > 1024) cap = 1024;
+        // the kernels below write nblk <= cap slabs: check the workspace BEFORE anything is queued (advisor, round 3)
+        if (wgrad_ws_floats(cap, KN) > ws_floats) {
+            while (cap > 1 && wgrad_ws_floats(cap, KN) > ws_floats) --cap;
+            if (wgrad_ws_floats(cap, KN) > ws_floats) return (int)hipErrorInvalidValue;
+        }
         int launched = 0, nblk = 0;
 #define PWW(LANES, COUT, VPL)                                                                                                         \
         do {                                                                                                                           \

@@ -282,7 +282,10 @@ static int conv16_tile(const ConvParams& p) {
     const long mt = (p.M + 255) / 256;
     int bn = p.Cout > 128 ? 256 : (p.Cout > 64 ? 128 : 64);
     if (force > 0) bn = force;
-    if (force < 0 && g_conv16_mode != 2 && mt * ((p.Cout + bn - 1) / bn) < 192) return 0;       // fewer than 3/4 of a wave of blocks on 256 CUs
+    // mode 1: only where it measured faster than conv_fast_kernel (tools/conv16_bench.py, profiles/r04_conv16_ab.txt): at least 3/4 of a
+    // wave of 256-pixel blocks on the 256 CUs, and more than 64 output channels (with a 64-wide tile every wave re-reads the whole weight
+    // tile: LDS-read bound, 0.6 - 0.9 x the 128 x 64 tile of the register-staged kernel, which runs 3 blocks per CU)
+    if (force < 0 && g_conv16_mode != 2 && (mt * ((p.Cout + bn - 1) / bn) < 192 || bn == 64)) return 0;
     return bn;
 }
 template <int PREC>
@@ -293,5 +296,231 @@ static int launch_conv16_prec(const ConvParams& p_, int bn, hipStream_t st) {
     if (bn == 256) hipLaunchKernelGGL((conv16_kernel<256, 256, 2, 4, 2, PREC>), dim3(ntm * ((p.Cout + 255) / 256)), dim3(512), 0, st, p);
     else if (bn == 128) hipLaunchKernelGGL((conv16_kernel<256, 128, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv16_kernel<256, 64, 4, 1, 3, PREC>), dim3(ntm * ((p.Cout + 63) / 64)), dim3(256), 0, st, p);
+    return MMSEG_CHECK_LAUNCH();
+}
+
+// =====================================================================================================================================
+// conv16h: the 3x3 'same' stride-1 case with the activation patch RESIDENT in LDS.
+//
+// Measured on conv16_kernel (tools/abl_conv16.sh, profiles/r04_conv16_ablation.txt): per 64-deep K tile a 256 x 128 block moves 48 KB
+// through the CU's texture addresser (64 B/clk -> 768 cycles against 1 024 cycles of MFMA work), 32 KB of it activations -- and the nine
+// taps of a 64-channel chunk are nine shifted copies of the SAME pixels.  Here a block owns 8 image rows x 32 columns; per 64-channel
+// chunk the 10 x 34-pixel halo patch (43.5 KB) is brought into LDS once (1 KB pieces spread over the chunk's nine K tiles, into the
+// other of two patch buffers) and the A fragments of tap (kh, kw) are read from it at pixel (y + kh, x + kw): activation traffic / 6.6,
+// loads per wave and K tile 6 -> 3 (N = 128), no per-tap address or validity arithmetic on the load side at all (a patch pixel outside
+// the image has an out-of-range offset for the whole launch).  An MFMA tile's 32 rows are 32 consecutive pixels of one image row, so the
+// 16-lane groups of ds_read_b128 see 16 distinct (pixel & 15) residues for every tap shift: with the chunk swizzle (pixel >> 1) & 7 the
+// reads are conflict-free (same argument as for the weight rows).  Weights stream through a ring of NS stages as in conv16_kernel.
+// Geometry: W % 32 == 0, H % 8 == 0, C1 % 64 == C2 % 64 == 0, optional nearest x2 up-sampling of x1 and concatenation with x2.
+template <int BN, int WM, int WN, int NS, int PREC>
+__device__ __forceinline__ void conv16h_body(const ConvParams& p) {
+    constexpr int TH = 8, TW = 32, NW = WM * WN;
+    constexpr int TM = TH / WM, TN = BN / WN / 32;
+    constexpr int HWD = TW + 2, HP = (TH + 2) * HWD, NP = (HP + 7) / 8;      // patch: 34 pixels wide, 340 pixels, 43 pieces of 8
+    constexpr int PPW = (NP + NW - 1) / NW;                                   // patch pieces per wave (6)
+    constexpr int HALO = NP * 1024, BST = BN * 128, BG = BN / 8 / NW;
+    constexpr int KT = 64;
+    static_assert(NW == 8 && TH % WM == 0 && BN % (8 * NW) == 0 && PPW <= 9, "8 waves; one patch piece per wave and tap");
+    static_assert(2 * HALO + NS * BST <= 160 * 1024, "LDS");
+    typedef typename LowPrec<PREC>::V8 LV8;
+
+    __shared__ __attribute__((aligned(1024))) char smem[2 * HALO + NS * BST];
+    char* const bring = smem + 2 * HALO;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nblk = gridDim.x;
+    const int ntn = (p.Cout + BN - 1) / BN, ntm = nblk / ntn;
+    const int lb = xcd_remap(blockIdx.x, nblk);
+    const bool w_major = (long)p.K * p.Cout > (long)p.M * (p.C1 + p.C2);
+    const int mt = w_major ? lb % ntm : lb / ntn;
+    const int n0 = (w_major ? lb / ntm : lb % ntn) * BN;
+    const int tpr = p.W / TW, tpi = (p.H / TH) * tpr;
+    const int t_b = mt / tpi, t_r = mt - t_b * tpi;
+    const int y0 = (t_r / tpr) * TH, x0 = (t_r % tpr) * TW;
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
+                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.K * p.Cout * 2, 0x00020000);
+    constexpr int FAR = 0x40000000;
+
+    // ---- patch pieces of this lane: piece pc = jj * NW + wid (jj = the tap during which it is loaded), pixel hp = 8 pc + (lane >> 3),
+    // LDS chunk (lane & 7) <- source chunk (lane & 7) ^ ((hp >> 1) & 7); byte offsets in x1 / x2, FAR for pixels outside the image
+    int h_o1[PPW], h_o2[PPW];
+#pragma unroll
+    for (int jj = 0; jj < PPW; ++jj) {
+        const int pc = jj * NW + wid;
+        const int hp = 8 * pc + (lane >> 3);
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const int sc16 = 16 * ((lane & 7) ^ ((hp >> 1) & 7));
+        const bool ok = hp < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        h_o1[jj] = ok ? (p.ups ? ((t_b * p.H1 + (y >> 1)) * p.W1 + (x >> 1)) : ((t_b * p.H + y) * p.W + x)) * p.C1 * 2 + sc16 : FAR;
+        h_o2[jj] = (ok && p.C2) ? ((t_b * p.H + y) * p.W + x) * p.C2 * 2 + sc16 : FAR;
+    }
+    int b_o[BG];
+#pragma unroll
+    for (int j = 0; j < BG; ++j) {
+        const int g = wid * BG + j;
+        const int n = n0 + 8 * g + (lane >> 3);
+        b_o[j] = n < p.Cout ? (n * p.K + 8 * ((lane & 7) ^ ((4 * g + (lane >> 4)) & 7))) * 2 : FAR;
+    }
+    const int Cin2 = (p.C1 + p.C2) * 2;
+    const int nch = (p.C1 + p.C2) / KT, nkt = nch * 9;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // one patch piece of chunk c (wave-uniform guards: the piece exists, the chunk exists) -> 1 if a load was issued
+    auto issue_patch = [&](const int c, const int jj) -> int {
+        if (c >= nch || jj >= PPW || jj * NW + wid >= NP) return 0;
+        char* dst = smem + (c & 1) * HALO + (jj * NW + wid) * 1024;
+        const int c0 = c * KT;
+        int off = 0;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) if (q == jj) off = c0 < p.C1 ? h_o1[q] : h_o2[q];      // (static register names)
+        if (c0 < p.C1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, off + c0 * 2, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr)dst, 16, off + (c0 - p.C1) * 2, 0, 0, 0);
+        return 1;
+    };
+    auto issue_b = [&](const int stage, const int c, const int tap, const bool live) {
+        char* dst = bring + stage * BST + wid * (BG * 1024);
+        const int koff = live ? tap * Cin2 + c * (KT * 2) : FAR;
+#pragma unroll
+        for (int j = 0; j < BG; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + j * 1024), 16, b_o[j] + koff, 0, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int b_col = wn * (BN / WN) + li;
+    // A fragment of row-block i (image row y0 + wm * TM + i), tap (kh, kw), k-step q: patch pixel hp = (wm TM + i + kh) * 34 + li + kw,
+    // chunk (2 q + lh) ^ key with key = (hp >> 1) & 7 = (row + ((li + kw) >> 1)) & 7 (34 row is even, 17 = 1 mod 8)
+    auto mma_tile = [&](const int hbuf, const int stage, const int kh, const int kw) {
+        const char* P = smem + hbuf * HALO;
+        const char* Bt = bring + stage * BST;
+        int abase[TM], akey[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int hp = (wm * TM + i + kh) * HWD + li + kw;
+            abase[i] = hp * 128;
+            akey[i] = (hp >> 1) & 7;
+        }
+        LV8 a[2][TM], b[2][TN];
+        auto frags = [&](const int set, const int q) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = b_col + j * 32;
+                b[set][j] = *reinterpret_cast<const LV8*>(Bt + row * 128 + 16 * ((2 * q + lh) ^ ((row >> 1) & 7)));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[set][i] = *reinterpret_cast<const LV8*>(P + abase[i] + 16 * ((2 * q + lh) ^ akey[i]));
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int q = 0; q < KT / 16; ++q) {
+            if (q + 1 < KT / 16) frags((q + 1) & 1, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = LowPrec<PREC>::mfma(a[q & 1][i], b[q & 1][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: the whole patch of chunk 0, the first NS - 1 weight tiles
+#pragma unroll
+    for (int jj = 0; jj < PPW; ++jj) issue_patch(0, jj);
+    issue_b(0, 0, 0, true);
+    if constexpr (NS == 3) {
+        issue_b(1, 0, 1, true);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BG) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // position of K tile t: chunk c, tap (kh, kw); of the weight tile issued in iteration t (tile t + NS - 1): (ci, ti)
+    int c = 0, kh = 0, kw = 0, tap = 0;
+    int ci = 0, ti = NS - 1;
+    int cur = 0, nxt = NS - 1;
+    const bool mma_first = wid >= NW / 2;      // SIMD partners queue loads and MFMAs in opposite order (conv16_kernel)
+    for (int t = 0; t < nkt; ++t) {
+        int hp_issued = 0;
+        if (!mma_first) { hp_issued = issue_patch(c + 1, tap); issue_b(nxt, ci, ti, t + NS - 1 < nkt); }
+        mma_tile(c & 1, cur, kh, kw);
+        if (mma_first) { hp_issued = issue_patch(c + 1, tap); issue_b(nxt, ci, ti, t + NS - 1 < nkt); }
+        // weight tile t + 1 was queued one iteration ago; younger than it are this iteration's patch piece and weight tile.  The
+        // patch pieces of chunk c + 1 are all older than the weight tile awaited at the end of tap 8 (the last one is queued at tap
+        // PPW - 1 <= 5): in-order retirement covers them.
+        if constexpr (NS == 3) {
+            if (hp_issued) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(BG + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(BG) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
+        ++tap;
+        if (++kw == 3) { kw = 0; if (++kh == 3) { kh = 0; tap = 0; ++c; } }
+        if (++ti == 9) { ti = 0; ++ci; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: accumulator tile (i, j) = 32 pixels of image row y0 + wm TM + i x 32 channels; quad-transposed 4-channel stores
+    {
+        const int tq = lane & 3;
+        const int c1 = p.y2 == nullptr ? p.Cout : p.nsplit1, c2 = p.Cout - c1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + li;
+            const bool nok = n < p.Cout;
+            const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+            const float sv = (nok && p.oscale) ? p.oscale[n] : 1.f;
+            const int nq = n - tq;
+            const bool first = nq < c1;
+            char* const obase = reinterpret_cast<char*>(first ? (void*)p.y : (void*)p.y2);
+            const int ocol = first ? nq : nq - c1, ocn = first ? c1 : c2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mrow = (t_b * p.H + y0 + wm * TM + i) * p.W + x0 + 4 * lh + tq;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float a[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = act_apply(acc[i][j][4 * g + e] * sv + bv, p.act, p.alpha);
+                    quad_transpose4(a, tq);
+                    if (!nok) continue;
+                    store4_out(obase, (size_t)(mrow + 8 * g) * ocn + ocol, a, p.io);
+                }
+            }
+        }
+    }
+}
+template <int BN, int WM, int WN, int NS, int PREC>
+__global__ __launch_bounds__(512, 2) void conv16h_kernel(ConvParams p) {
+    conv16h_body<BN, WM, WN, NS, PREC>(p);
+}
+// applicability of the patch-resident kernel; 0 or the N tile
+static int conv16h_tile(const ConvParams& p) {
+    if (g_conv16_mode == 0) return 0;
+    static const int hmode = ab_int("MMSEG_CONV16H", 1);     // measurement builds: 0 = never
+    if (!hmode) return 0;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1 || p.Ho != p.H || p.Wo != p.W) return 0;
+    if (p.W % 32 || p.H % 8) return 0;
+    const int bn = p.Cout > 128 ? 256 : (p.Cout > 64 ? 128 : 64);
+    if (g_conv16_mode != 2 && ((long)(p.M / 256) * ((p.Cout + bn - 1) / bn) < 192 || bn == 64)) return 0;
+    return bn;
+}
+template <int PREC>
+static int launch_conv16h_prec(const ConvParams& p, int bn, hipStream_t st) {
+    const int ntm = p.M / 256;
+    if (bn == 256) hipLaunchKernelGGL((conv16h_kernel<256, 2, 4, 2, PREC>), dim3(ntm * ((p.Cout + 255) / 256)), dim3(512), 0, st, p);
+    else if (bn == 128) hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv16h_kernel<64, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 63) / 64)), dim3(512), 0, st, p);
     return MMSEG_CHECK_LAUNCH();
 }

@@ -1116,7 +1116,10 @@ class _Conv2dPair(torch.autograd.Function):
         wcat, bcat = _pair_operands(wa, ba, wb, bb, wkey)
         pkey = (('pair',) + tuple(wkey[:1]), wkey[1]) if isinstance(wkey, tuple) else None
         wt = _wprep(wcat, KH, KW, Cin, Cout, 0, pkey) if N.call('mmseg_conv2d_fast_path', Cin, 0, Cout, 0) else None
-        y = _new((B, H, W, Cout), x, out_dtype if wt is not None else torch.float32)     # (16-bit outputs: fast path only)
+        # 16-bit outputs need the fast path in BOTH directions: the backward pass reads the 16-bit dy and writes a 16-bit dx through
+        # the fast path of the Cout -> Cin convolution (advisor, round 3: 2f % 32 != 0 sent a 16-bit dy to the generic kernel)
+        bwd_fast = bool(N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0))
+        y = _new((B, H, W, Cout), x, out_dtype if (wt is not None and bwd_fast) else torch.float32)
         _conv_fwd_raw(x, None, wcat, wt, bcat, y, None, B, H, W, Cin, 0, H, W, Cout, KH, KW, 1, KH // 2, KW // 2, 0, 0, 0, 0.0, 0)
         ctx.geom = (B, H, W, Cin, Ca, Cb, KH, KW)
         ctx.grads, ctx.pkey = grads, pkey
@@ -1146,10 +1149,13 @@ class _Conv2dPair(torch.autograd.Function):
         _grad_done(wga, bga, wgb, bgb)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _new((B, H, W, Cin), dy, x.dtype)          # a gradient is stored like its tensor
             # (a model's operands come out of the cache; anonymous ones are concatenated again: their scratch may have been reused)
             wcat = _pair_operands(*ctx.operands)[0]
-            if N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0):
+            fastb = bool(N.call('mmseg_conv2d_fast_path', Cout, 0, Cin, 0))
+            if not fastb and _h(dy):
+                dy = dy.float()                             # (unreachable with the forward's choice of out_dtype; kept as a guard)
+            dx = _new((B, H, W, Cin), dy, x.dtype if (fastb or _h(x) == 0) else torch.float32)      # a gradient is stored like its tensor
+            if fastb:
                 wf, wt = None, _wprep(wcat, KH, KW, Cin, Cout, 1, ctx.pkey)
             else:
                 wf, wt = _ws('wflip', wcat.numel(), dy.device)[:wcat.numel()], None
