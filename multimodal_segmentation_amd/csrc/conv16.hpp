@@ -312,7 +312,11 @@ static int launch_conv16_prec(const ConvParams& p_, int bn, hipStream_t st) {
 // 16-lane groups of ds_read_b128 see 16 distinct (pixel & 15) residues for every tap shift: with the chunk swizzle (pixel >> 1) & 7 the
 // reads are conflict-free (same argument as for the weight rows).  Weights stream through a ring of NS stages as in conv16_kernel.
 // Geometry: W % 32 == 0, H % 8 == 0, C1 % 64 == C2 % 64 == 0, optional nearest x2 up-sampling of x1 and concatenation with x2.
-template <int BN, int WM, int WN, int NS, int PREC>
+// SUP = K tiles per barrier.  SUP = 2 (N tiles of 128 / 64 channels: their weight stages are small enough for four ring slots): two taps
+// are queued, multiplied (one chain of 8 k-steps: the fragment pipeline does not restart between them) and awaited together -- 32 / 16
+// MFMAs per wave between two barriers instead of 16 / 8.  The patch piece loaded during tap t is piece t - 2 (taps 2 .. 7): a chunk's
+// first tap may share a barrier interval with the previous chunk's last tap, which still reads the buffer being refilled.
+template <int BN, int WM, int WN, int NS, int PREC, int SUP = 1>
 __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
     constexpr int TH = 8, TW = 32, NW = WM * WN;
     constexpr int TM = TH / WM, TN = BN / WN / 32;
@@ -320,11 +324,14 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
     constexpr int PPW = (NP + NW - 1) / NW;                                   // patch pieces per wave (6)
     constexpr int HALO = NP * 1024, BST = BN * 128, BG = BN / 8 / NW;
     constexpr int KT = 64;
-    static_assert(NW == 8 && TH % WM == 0 && BN % (8 * NW) == 0 && PPW <= 9, "8 waves; one patch piece per wave and tap");
-    static_assert(2 * HALO + NS * BST <= 160 * 1024, "LDS");
+    constexpr int NST = NS * SUP;                                              // ring slots (one K tile each)
+    constexpr int PT0 = SUP > 1 ? 2 : 0;                                       // first tap during which a patch piece is loaded
+    static_assert(NW == 8 && TH % WM == 0 && BN % (8 * NW) == 0 && PT0 + PPW <= 9, "8 waves; one patch piece per wave and tap");
+    static_assert(SUP == 1 || NS == 2, "several tiles per barrier: everything queued is awaited at the barrier");
+    static_assert(2 * HALO + NST * BST <= 160 * 1024, "LDS");
     typedef typename LowPrec<PREC>::V8 LV8;
 
-    __shared__ __attribute__((aligned(1024))) char smem[2 * HALO + NS * BST];
+    __shared__ __attribute__((aligned(1024))) char smem[2 * HALO + NST * BST];
     char* const bring = smem + 2 * HALO;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -400,74 +407,96 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
 
     const int b_col = wn * (BN / WN) + li;
     // A fragment of row-block i (image row y0 + wm * TM + i), tap (kh, kw), k-step q: patch pixel hp = (wm TM + i + kh) * 34 + li + kw,
-    // chunk (2 q + lh) ^ key with key = (hp >> 1) & 7 = (row + ((li + kw) >> 1)) & 7 (34 row is even, 17 = 1 mod 8)
-    auto mma_tile = [&](const int hbuf, const int stage, const int kh, const int kw) {
-        const char* P = smem + hbuf * HALO;
-        const char* Bt = bring + stage * BST;
-        int abase[TM], akey[TM];
+    // chunk (2 q + lh) ^ key with key = (hp >> 1) & 7.  SUP tiles form one chain of 4 SUP k-steps.
+    struct Tile { int hbuf, slot, kh, kw; bool live; };
+    auto mma_tiles = [&](const Tile (&tl)[SUP]) {
+        int abase[SUP][TM], akey[SUP][TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int hp = (wm * TM + i + kh) * HWD + li + kw;
-            abase[i] = hp * 128;
-            akey[i] = (hp >> 1) & 7;
-        }
+        for (int u = 0; u < SUP; ++u)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int hp = (wm * TM + i + tl[u].kh) * HWD + li + tl[u].kw;
+                abase[u][i] = tl[u].hbuf * HALO + hp * 128;
+                akey[u][i] = (hp >> 1) & 7;
+            }
         LV8 a[2][TM], b[2][TN];
-        auto frags = [&](const int set, const int q) {
+        auto frags = [&](const int set, const int qq) {
+            const int u = qq / 4, q = qq % 4;
+            const char* Bt = bring + tl[u].slot * BST;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = b_col + j * 32;
                 b[set][j] = *reinterpret_cast<const LV8*>(Bt + row * 128 + 16 * ((2 * q + lh) ^ ((row >> 1) & 7)));
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[set][i] = *reinterpret_cast<const LV8*>(P + abase[i] + 16 * ((2 * q + lh) ^ akey[i]));
+            for (int i = 0; i < TM; ++i) a[set][i] = *reinterpret_cast<const LV8*>(smem + abase[u][i] + 16 * ((2 * q + lh) ^ akey[u][i]));
         };
         frags(0, 0);
 #pragma unroll
-        for (int q = 0; q < KT / 16; ++q) {
-            if (q + 1 < KT / 16) frags((q + 1) & 1, q + 1);
+        for (int qq = 0; qq < 4 * SUP; ++qq) {
+            if (qq + 1 < 4 * SUP) frags((qq + 1) & 1, qq + 1);
             __builtin_amdgcn_sched_barrier(0);
+            if (SUP == 1 || tl[qq / 4].live) {           // (a tile beyond K: its slot and patch hold finite data, the products are skipped)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = LowPrec<PREC>::mfma(a[q & 1][i], b[q & 1][j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = LowPrec<PREC>::mfma(a[qq & 1][i], b[qq & 1][j], acc[i][j]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // ---- prologue: the whole patch of chunk 0, the first NS - 1 weight tiles
+    // ---- prologue: the whole patch of chunk 0, the first (NS - 1) SUP weight tiles
 #pragma unroll
     for (int jj = 0; jj < PPW; ++jj) issue_patch(0, jj);
-    issue_b(0, 0, 0, true);
-    if constexpr (NS == 3) {
-        issue_b(1, 0, 1, true);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BG) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    // position of K tile t: chunk c, tap (kh, kw); of the weight tile issued in iteration t (tile t + NS - 1): (ci, ti)
+#pragma unroll
+    for (int u = 0; u < (NS - 1) * SUP; ++u) issue_b(u, u / 9, u % 9, u < nkt);
+    if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BG) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // position of K tile t: chunk c, tap (kh, kw); of the first weight tile queued in this interval (tile t + (NS - 1) SUP): (ci, ti)
     int c = 0, kh = 0, kw = 0, tap = 0;
-    int ci = 0, ti = NS - 1;
-    int cur = 0, nxt = NS - 1;
+    int ci = ((NS - 1) * SUP) / 9, ti = ((NS - 1) * SUP) % 9;
+    int cur = 0, nxt = ((NS - 1) * SUP) % NST;
     const bool mma_first = wid >= NW / 2;      // SIMD partners queue loads and MFMAs in opposite order (conv16_kernel)
-    for (int t = 0; t < nkt; ++t) {
+    for (int t = 0; t < nkt; t += SUP) {
+        Tile tl[SUP];
+        int pc_[SUP], pt_[SUP];                // (chunk whose patch is being filled, piece) per tile of the interval
+        {
+            int c_ = c, kh_ = kh, kw_ = kw, tap_ = tap, slot = cur;
+#pragma unroll
+            for (int u = 0; u < SUP; ++u) {
+                tl[u].hbuf = c_ & 1; tl[u].slot = slot; tl[u].kh = kh_; tl[u].kw = kw_; tl[u].live = t + u < nkt;
+                pc_[u] = c_ + 1; pt_[u] = tap_ - PT0;
+                slot = slot + 1 == NST ? 0 : slot + 1;
+                ++tap_;
+                if (++kw_ == 3) { kw_ = 0; if (++kh_ == 3) { kh_ = 0; tap_ = 0; ++c_; } }
+            }
+            c = c_; kh = kh_; kw = kw_; tap = tap_; cur = slot;
+        }
         int hp_issued = 0;
-        if (!mma_first) { hp_issued = issue_patch(c + 1, tap); issue_b(nxt, ci, ti, t + NS - 1 < nkt); }
-        mma_tile(c & 1, cur, kh, kw);
-        if (mma_first) { hp_issued = issue_patch(c + 1, tap); issue_b(nxt, ci, ti, t + NS - 1 < nkt); }
-        // weight tile t + 1 was queued one iteration ago; younger than it are this iteration's patch piece and weight tile.  The
-        // patch pieces of chunk c + 1 are all older than the weight tile awaited at the end of tap 8 (the last one is queued at tap
-        // PPW - 1 <= 5): in-order retirement covers them.
+        auto issue_all = [&]() {
+            int ci_ = ci, ti_ = ti, slot = nxt;
+#pragma unroll
+            for (int u = 0; u < SUP; ++u) {
+                if (pt_[u] >= 0 && tl[u].live) hp_issued += issue_patch(pc_[u], pt_[u]);
+                issue_b(slot, ci_, ti_, t + (NS - 1) * SUP + u < nkt);
+                slot = slot + 1 == NST ? 0 : slot + 1;
+                if (++ti_ == 9) { ti_ = 0; ++ci_; }
+            }
+            ci = ci_; ti = ti_; nxt = slot;
+        };
+        if (!mma_first) issue_all();
+        mma_tiles(tl);
+        if (mma_first) issue_all();
+        // NS == 3 (SUP == 1): weight tile t + 1 was queued one interval ago; younger than it are this interval's patch piece and weight
+        // tile; the patch pieces of chunk c + 1 are all older than the weight tile awaited at the end of tap 8 (in-order retirement).
+        // NS == 2: everything queued is awaited.
         if constexpr (NS == 3) {
             if (hp_issued) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(BG + 1) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(BG) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        cur = cur + 1 == NS ? 0 : cur + 1;
-        nxt = nxt + 1 == NS ? 0 : nxt + 1;
-        ++tap;
-        if (++kw == 3) { kw = 0; if (++kh == 3) { kh = 0; tap = 0; ++c; } }
-        if (++ti == 9) { ti = 0; ++ci; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -501,9 +530,9 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
         }
     }
 }
-template <int BN, int WM, int WN, int NS, int PREC>
+template <int BN, int WM, int WN, int NS, int PREC, int SUP = 1>
 __global__ __launch_bounds__(512, 2) void conv16h_kernel(ConvParams p) {
-    conv16h_body<BN, WM, WN, NS, PREC>(p);
+    conv16h_body<BN, WM, WN, NS, PREC, SUP>(p);
 }
 // applicability of the patch-resident kernel; 0 or the N tile
 static int conv16h_tile(const ConvParams& p) {
@@ -520,6 +549,14 @@ template <int PREC>
 static int launch_conv16h_prec(const ConvParams& p, int bn, hipStream_t st) {
     const int ntm = p.M / 256;
     if (bn == 256) hipLaunchKernelGGL((conv16h_kernel<256, 2, 4, 2, PREC>), dim3(ntm * ((p.Cout + 255) / 256)), dim3(512), 0, st, p);
+    // (two K tiles per barrier, SUP = 2, measured within +-2 % of one per barrier on every shape -- tools/ab_sup.sh, profiles/r04_conv16_notes.txt
+    // -- so the product keeps the smaller-LDS three-stage form; the SUP = 2 instances exist in measurement builds only)
+#ifdef MMSEG_AB
+    else if (ab_int("MMSEG_CONV16H_SUP", 1) == 2 && bn == 128)
+        hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 2, PREC, 2>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
+    else if (ab_int("MMSEG_CONV16H_SUP", 1) == 2)
+        hipLaunchKernelGGL((conv16h_kernel<64, 4, 2, 2, PREC, 2>), dim3(ntm * ((p.Cout + 63) / 64)), dim3(512), 0, st, p);
+#endif
     else if (bn == 128) hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv16h_kernel<64, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 63) / 64)), dim3(512), 0, st, p);
     return MMSEG_CHECK_LAUNCH();
