@@ -51,6 +51,14 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
 def kernel_name(kid, prec):
     """mmseg_conv2d_last_kernel() id -> the kernel name rocprofv3 reports (template arguments included)"""
     fam, rest = kid // 1000000, kid % 1000000
+    if fam in (16, 17):        # the large-tile 16-bit kernels: plain <pixels per block> * 1000 + <N tile> (no flag fields)
+        bm, bn = rest // 1000, rest % 1000
+        if fam == 16:          # <M tile, N tile, waves M, waves N, ring stages, precision>
+            return 'conv16_kernel<256, %d, %d, %d, %d, %d>' % (bn, 2 if bn == 256 else 4, 4 if bn == 256 else (2 if bn == 128 else 1),
+                                                              2 if bn == 256 else 3, prec)
+        rows = bm // 32        # <N tile, waves M, waves N, ring stages, precision, K tiles per barrier, image rows, patch buffers>
+        wm_, wn_ = (8, 1) if bn == 64 else ((2, 4) if bn == 256 else (4, 2))
+        return 'conv16h_kernel<%d, %d, %d, %d, %d, 1, %d, %d>' % (bn, wm_, wn_, 2 if bn == 256 else 3, prec, rows, 1 if rows == 16 else 2)
     flag, rest = rest // 500000, rest % 500000
     k64, rest = rest // 250000, rest % 250000
     bm, bn = rest // 1000, rest % 1000

@@ -781,7 +781,7 @@ static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
 // M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / 16-bit input of the fast kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
 // 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel,
 // 10 pw_reduce_kernel<LANES, COUT, VPL>, 12 pw_reduce_wgrad_kernel<...> (M tile field = LANES, N tile field = COUT);
-// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv16_kernel, 15 conv16h_kernel
+// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv_wgrad_tr_anyw_kernel; 16 conv16_kernel, 17 conv16h_kernel (M tile field = pixels per block)
 static int g_last_kernel = 0;
 #define MMSEG_SET_LAST(fam, bm, bn) (g_last_kernel = (fam) * 1000000 + (bm) * 1000 + (bn))
 template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false>
@@ -1104,14 +1104,14 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
                                                                      // that only prepared `wt` must not fall through to them
     if (fast && g_conv_bf16 != 0) {
         // 16-bit tensors, channel counts multiples of 64, enough pixels: the large-tile direct-to-LDS kernel (conv16.hpp)
-        const int bn = conv16_tile(p);
-        const int bnh = bn ? conv16h_tile(p) : 0;            // 3x3 'same': the activation patch stays in LDS across the nine taps
+        const int bnh = conv16h_tile(p);                     // 3x3 'same': the activation patch stays in LDS across the nine taps
+        const int bn = bnh ? 0 : conv16_tile(p);
         if (bnh) {
-            MMSEG_SET_LAST(15, 256, bnh);
+            MMSEG_SET_LAST(17, conv16h_rows(p, bnh) * 32, bnh);
             return g_conv_bf16 == 1 ? launch_conv16h_prec<1>(p, bnh, st) : launch_conv16h_prec<2>(p, bnh, st);
         }
         if (bn) {
-            MMSEG_SET_LAST(14, 256, bn);
+            MMSEG_SET_LAST(16, 256, bn);
             return g_conv_bf16 == 1 ? launch_conv16_prec<1>(p, bn, st) : launch_conv16_prec<2>(p, bn, st);
         }
     }

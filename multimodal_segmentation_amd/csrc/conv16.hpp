@@ -272,11 +272,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void conv16_kernel(ConvP
 // 0: never use this kernel; 1 (default): where it pays; 2: wherever it applies (tests put small problems on it) -- mmseg_conv16_mode
 static int g_conv16_mode = 1;
 // tile choice.  0 = leave the layer to conv_fast_kernel (too few 256-pixel tiles to fill the chip, or K tiles that straddle tensors)
-static int conv16_tile(const ConvParams& p) {
-    if (g_conv16_mode == 0) return 0;
-    if (!(p.io & 1) || (p.C2 && !(p.io & 2)) || p.C1 % 64 || p.C2 % 64 || p.Cout % 8 || p.KH * p.KW > 30) return 0;
+// what both kernels need: 16-bit inputs, channel counts multiples of 64 (a K tile inside one tap of one tensor), no output mapping,
+// aligned outputs (the lean epilogue)
+static bool conv16_applicable(const ConvParams& p) {
+    if (g_conv16_mode == 0) return false;
+    if (!(p.io & 1) || (p.C2 && !(p.io & 2)) || p.C1 % 64 || p.C2 % 64 || p.Cout % 8 || p.KH * p.KW > 30) return false;
     const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
-    if (omap || !p.qepi || (p.y2 != nullptr && p.nsplit1 % 4)) return 0;      // (what the lean epilogue does not handle)
+    return !(omap || !p.qepi || (p.y2 != nullptr && p.nsplit1 % 4));
+}
+static int conv16_tile(const ConvParams& p) {
+    if (!conv16_applicable(p)) return 0;
     static const int force = ab_int("MMSEG_CONV16", -1);      // measurement builds: 0 off, 64 / 128 / 256 force a tile
     if (force == 0) return 0;
     const long mt = (p.M + 255) / 256;
@@ -316,9 +321,13 @@ static int launch_conv16_prec(const ConvParams& p_, int bn, hipStream_t st) {
 // are queued, multiplied (one chain of 8 k-steps: the fragment pipeline does not restart between them) and awaited together -- 32 / 16
 // MFMAs per wave between two barriers instead of 16 / 8.  The patch piece loaded during tap t is piece t - 2 (taps 2 .. 7): a chunk's
 // first tap may share a barrier interval with the previous chunk's last tap, which still reads the buffer being refilled.
-template <int BN, int WM, int WN, int NS, int PREC, int SUP = 1>
+// TH = image rows per block (8 or 16), PB = patch buffers.  The 64-channel N tile uses 16 rows x 32 columns with the 8 waves stacked along M
+// (a wave: 2 image rows x 64 channels = the 2 x 2 accumulator tiles of the 128-channel form, 4 fragment reads per 4 MFMAs; with 8 rows a wave
+// would own 64 x 32 outputs and read 3 fragments per 2 MFMAs -- LDS-read bound, 0.9 x conv_fast_kernel).  Its 18 x 34 patch (77 KB) is single
+// buffered (PB = 1): at a chunk boundary the block reloads it behind a barrier; the N = 64 layers have one or two 64-channel chunks.
+template <int BN, int WM, int WN, int NS, int PREC, int SUP = 1, int TH = 8, int PB = 2>
 __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
-    constexpr int TH = 8, TW = 32, NW = WM * WN;
+    constexpr int TW = 32, NW = WM * WN;
     constexpr int TM = TH / WM, TN = BN / WN / 32;
     constexpr int HWD = TW + 2, HP = (TH + 2) * HWD, NP = (HP + 7) / 8;      // patch: 34 pixels wide, 340 pixels, 43 pieces of 8
     constexpr int PPW = (NP + NW - 1) / NW;                                   // patch pieces per wave (6)
@@ -326,13 +335,14 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
     constexpr int KT = 64;
     constexpr int NST = NS * SUP;                                              // ring slots (one K tile each)
     constexpr int PT0 = SUP > 1 ? 2 : 0;                                       // first tap during which a patch piece is loaded
-    static_assert(NW == 8 && TH % WM == 0 && BN % (8 * NW) == 0 && PT0 + PPW <= 9, "8 waves; one patch piece per wave and tap");
+    static_assert(NW == 8 && TH % WM == 0 && BN % (8 * NW) == 0 && (PB == 1 || PT0 + PPW <= 9), "8 waves; one patch piece per wave and tap");
+    static_assert(PB == 2 || SUP == 1, "single patch buffer: one K tile per barrier");
     static_assert(SUP == 1 || NS == 2, "several tiles per barrier: everything queued is awaited at the barrier");
-    static_assert(2 * HALO + NST * BST <= 160 * 1024, "LDS");
+    static_assert(PB * HALO + NST * BST <= 160 * 1024, "LDS");
     typedef typename LowPrec<PREC>::V8 LV8;
 
-    __shared__ __attribute__((aligned(1024))) char smem[2 * HALO + NST * BST];
-    char* const bring = smem + 2 * HALO;
+    __shared__ __attribute__((aligned(1024))) char smem[PB * HALO + NST * BST];
+    char* const bring = smem + PB * HALO;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
@@ -381,7 +391,7 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
     // one patch piece of chunk c (wave-uniform guards: the piece exists, the chunk exists) -> 1 if a load was issued
     auto issue_patch = [&](const int c, const int jj) -> int {
         if (c >= nch || jj >= PPW || jj * NW + wid >= NP) return 0;
-        char* dst = smem + (c & 1) * HALO + (jj * NW + wid) * 1024;
+        char* dst = smem + (PB == 2 ? (c & 1) * HALO : 0) + (jj * NW + wid) * 1024;
         const int c0 = c * KT;
         int off = 0;
 #pragma unroll
@@ -465,7 +475,7 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
             int c_ = c, kh_ = kh, kw_ = kw, tap_ = tap, slot = cur;
 #pragma unroll
             for (int u = 0; u < SUP; ++u) {
-                tl[u].hbuf = c_ & 1; tl[u].slot = slot; tl[u].kh = kh_; tl[u].kw = kw_; tl[u].live = t + u < nkt;
+                tl[u].hbuf = PB == 2 ? (c_ & 1) : 0; tl[u].slot = slot; tl[u].kh = kh_; tl[u].kw = kw_; tl[u].live = t + u < nkt;
                 pc_[u] = c_ + 1; pt_[u] = tap_ - PT0;
                 slot = slot + 1 == NST ? 0 : slot + 1;
                 ++tap_;
@@ -473,12 +483,22 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
             }
             c = c_; kh = kh_; kw = kw_; tap = tap_; cur = slot;
         }
+        if constexpr (PB == 1) {
+            if (tl[0].kh == 0 && tl[0].kw == 0 && t > 0) {
+                // a new 64-channel chunk: every wave has finished the previous chunk's taps (barrier of the last iteration); refill the
+                // one patch buffer and wait for it -- the only point where this form exposes a load latency inside the K loop
+                const int cn = t / 9;
+#pragma unroll
+                for (int jj = 0; jj < PPW; ++jj) issue_patch(cn, jj);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
         int hp_issued = 0;
         auto issue_all = [&]() {
             int ci_ = ci, ti_ = ti, slot = nxt;
 #pragma unroll
             for (int u = 0; u < SUP; ++u) {
-                if (pt_[u] >= 0 && tl[u].live) hp_issued += issue_patch(pc_[u], pt_[u]);
+                if (PB == 2 && pt_[u] >= 0 && tl[u].live) hp_issued += issue_patch(pc_[u], pt_[u]);
                 issue_b(slot, ci_, ti_, t + (NS - 1) * SUP + u < nkt);
                 slot = slot + 1 == NST ? 0 : slot + 1;
                 if (++ti_ == 9) { ti_ = 0; ++ci_; }
@@ -530,20 +550,35 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
         }
     }
 }
-template <int BN, int WM, int WN, int NS, int PREC, int SUP = 1>
+template <int BN, int WM, int WN, int NS, int PREC, int SUP = 1, int TH = 8, int PB = 2>
 __global__ __launch_bounds__(512, 2) void conv16h_kernel(ConvParams p) {
-    conv16h_body<BN, WM, WN, NS, PREC, SUP>(p);
+    conv16h_body<BN, WM, WN, NS, PREC, SUP, TH, PB>(p);
 }
 // applicability of the patch-resident kernel; 0 or the N tile
 static int conv16h_tile(const ConvParams& p) {
-    if (g_conv16_mode == 0) return 0;
+    if (!conv16_applicable(p)) return 0;
     static const int hmode = ab_int("MMSEG_CONV16H", 1);     // measurement builds: 0 = never
     if (!hmode) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1 || p.Ho != p.H || p.Wo != p.W) return 0;
     if (p.W % 32 || p.H % 8) return 0;
     const int bn = p.Cout > 128 ? 256 : (p.Cout > 64 ? 128 : 64);
-    if (g_conv16_mode != 2 && ((long)(p.M / 256) * ((p.Cout + bn - 1) / bn) < 192 || bn == 64)) return 0;
+    if (bn == 64) {                                          // 16 image rows per block (the 64-channel form)
+        static const int h64 = ab_int("MMSEG_CONV16H_N64", 1);
+        if (!h64 || p.H % 16) return 0;
+        if (g_conv16_mode != 2 && (long)(p.M / 512) < 192) return 0;
+        return 64;
+    }
+    if (g_conv16_mode != 2 && (long)(p.M / 256) * ((p.Cout + bn - 1) / bn) < 192) return 0;
     return bn;
+}
+// image rows per block of the patch-resident kernel for this launch: 16 for the 64-channel form; for 128 channels 16 where the image
+// and the grid allow (a wave then owns 4 rows x 64 channels = 128 x 64 outputs, 6 fragment reads per 8 MFMAs and 32 MFMAs between two
+// barriers: 1.17 - 1.21 x the 8-row form, tools/ab_th16.sh), else 8
+static int conv16h_rows(const ConvParams& p, int bn) {
+    if (bn == 64) return 16;
+    if (bn == 128 && p.H % 16 == 0 && ab_int("MMSEG_CONV16H_TH16", 1) &&
+        (g_conv16_mode == 2 || (long)(p.M / 512) * ((p.Cout + 127) / 128) >= 192)) return 16;
+    return 8;
 }
 template <int PREC>
 static int launch_conv16h_prec(const ConvParams& p, int bn, hipStream_t st) {
@@ -554,10 +589,10 @@ static int launch_conv16h_prec(const ConvParams& p, int bn, hipStream_t st) {
 #ifdef MMSEG_AB
     else if (ab_int("MMSEG_CONV16H_SUP", 1) == 2 && bn == 128)
         hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 2, PREC, 2>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
-    else if (ab_int("MMSEG_CONV16H_SUP", 1) == 2)
-        hipLaunchKernelGGL((conv16h_kernel<64, 4, 2, 2, PREC, 2>), dim3(ntm * ((p.Cout + 63) / 64)), dim3(512), 0, st, p);
 #endif
+    else if (bn == 128 && conv16h_rows(p, bn) == 16)
+        hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC, 1, 16, 1>), dim3((p.M / 512) * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
     else if (bn == 128) hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv16h_kernel<64, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 63) / 64)), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv16h_kernel<64, 8, 1, 3, PREC, 1, 16, 1>), dim3(p.M / 512), dim3(512), 0, st, p);
     return MMSEG_CHECK_LAUNCH();
 }

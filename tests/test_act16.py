@@ -341,13 +341,16 @@ def test_generator_step_with_16bit_trunk_storage_close_to_fp32_storage(dt, decod
     (1, 32, 32, 64, 64, 128, 3, 0, 1),      # two inputs (skip concatenation): K tiles walk x1, then x2
     (2, 16, 16, 192, 0, 320, 1, 0, 0),      # 1x1, Cout not a multiple of the tile
     (1, 20, 20, 64, 0, 72, 5, 0, 0),        # 5x5 taps, Cout = 72
-    # 3x3 'same' with W % 32 == 0 and H % 8 == 0: the patch-resident kernel (conv16h_kernel, family 15)
+    # 3x3 'same' with W % 32 == 0 and H % 8 == 0: the patch-resident kernel (conv16h_kernel, family 17)
     (2, 8, 32, 64, 0, 128, 3, 0, 2),        # one tile per image: every patch border lies outside the image
     (1, 24, 64, 128, 0, 256, 3, 0, 1),      # 3 x 2 tiles, interior borders, 256-wide N tile (2 weight stages)
     (3, 16, 32, 64, 0, 192, 3, 0, 0),       # Cout between the tile widths, batch 3
     (2, 16, 32, 128, 0, 64, 3, 1, 1),       # up-sampled x1 (stored 8 x 16)
     (1, 16, 64, 64, 128, 64, 3, 0, 0),      # concatenation: chunks walk x1 (1 chunk) then x2 (2 chunks)
     (1, 32, 32, 192, 0, 320, 3, 0, 0),      # three chunks, two N tiles of 256
+    (2, 32, 64, 64, 0, 64, 3, 0, 1),        # 64-channel form: 16 rows x 32 columns per block, one chunk
+    (1, 16, 32, 64, 128, 56, 3, 0, 2),      # ... three chunks (single patch buffer reloaded twice), Cout = 56
+    (2, 32, 32, 128, 0, 64, 3, 1, 0),       # ... up-sampled input, two chunks
 ])
 def test_large_tile_16bit_kernel_equals_the_register_staged_kernel(B, H, W, C1, C2, Cout, k, ups, act, mode):
     """conv16.hpp (256-pixel tiles, buffer_load ... lds, ring of LDS stages) forced onto small problems (mmseg_conv16_mode 2) against
@@ -375,8 +378,8 @@ def test_large_tile_16bit_kernel_equals_the_register_staged_kernel(B, H, W, C1, 
                        io_in | (4 if out16 else 0))
                 outs[(m16, out16)] = y
                 fam = N.call('mmseg_conv2d_last_kernel') // 1000000
-                hres = k == 3 and W % 32 == 0 and H % 8 == 0
-                assert fam == ((15 if hres else 14) if m16 == 2 else 1), 'launch went to kernel family %d' % fam
+                hres = k == 3 and W % 32 == 0 and H % (16 if Cout <= 64 else 8) == 0
+                assert fam == ((17 if hres else 16) if m16 == 2 else 1), 'launch went to kernel family %d' % fam
         # same operands, same MFMA; the K tiles are 64 channels deep here and 32 or 64 in the other kernel (its choice depends on the
         # tile): the fp32 sums differ by their association only
         scale = float(outs[(0, False)].abs().max())
