@@ -1115,6 +1115,14 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
             return g_conv_bf16 == 1 ? launch_conv16_prec<1>(p, bn, st) : launch_conv16_prec<2>(p, bn, st);
         }
     }
+    if (fast && g_conv_bf16 == 0) {
+        // fp32, 3x3 'same', enough pixels: the patch-resident large-tile kernel on the fp32 MFMA (conv16.hpp, PREC 0)
+        const int bnh = conv16h_tile(p, true);
+        if (bnh) {
+            MMSEG_SET_LAST(17, conv16h_rows(p, bnh) * 32, bnh);
+            return launch_conv16h_prec<0>(p, bnh, st);
+        }
+    }
     if (fast) {
         static const int force_tile = ab_int("MMSEG_FAST_TILE", 0);   // tile A/B measurements
         if (force_tile == 1) return launch_fast<128, 128, 2, 2>(p, st);

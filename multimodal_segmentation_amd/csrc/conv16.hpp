@@ -332,7 +332,8 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
     constexpr int HWD = TW + 2, HP = (TH + 2) * HWD, NP = (HP + 7) / 8;      // patch: 34 pixels wide, 340 pixels, 43 pieces of 8
     constexpr int PPW = (NP + NW - 1) / NW;                                   // patch pieces per wave (6)
     constexpr int HALO = NP * 1024, BST = BN * 128, BG = BN / 8 / NW;
-    constexpr int KT = 64;
+    constexpr int ES = PREC ? 2 : 4;                                           // bytes per element: 16-bit modes / fp32 (PREC 0)
+    constexpr int KT = 128 / ES;                                               // channels per chunk: one 128-byte LDS row per pixel
     constexpr int NST = NS * SUP;                                              // ring slots (one K tile each)
     constexpr int PT0 = SUP > 1 ? 2 : 0;                                       // first tap during which a patch piece is loaded
     static_assert(NW == 8 && TH % WM == 0 && BN % (8 * NW) == 0 && (PB == 1 || PT0 + PPW <= 9), "8 waves; one patch piece per wave and tap");
@@ -357,10 +358,10 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
     const int t_b = mt / tpi, t_r = mt - t_b * tpi;
     const int y0 = (t_r / tpr) * TH, x0 = (t_r % tpr) * TW;
 
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * ES, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
-                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * 2 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.K * p.Cout * 2, 0x00020000);
+                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * ES : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.K * p.Cout * ES, 0x00020000);
     constexpr int FAR = 0x40000000;
 
     // ---- patch pieces of this lane: piece pc = jj * NW + wid (jj = the tap during which it is loaded), pixel hp = 8 pc + (lane >> 3),
@@ -374,17 +375,17 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         const int sc16 = 16 * ((lane & 7) ^ ((hp >> 1) & 7));
         const bool ok = hp < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        h_o1[jj] = ok ? (p.ups ? ((t_b * p.H1 + (y >> 1)) * p.W1 + (x >> 1)) : ((t_b * p.H + y) * p.W + x)) * p.C1 * 2 + sc16 : FAR;
-        h_o2[jj] = (ok && p.C2) ? ((t_b * p.H + y) * p.W + x) * p.C2 * 2 + sc16 : FAR;
+        h_o1[jj] = ok ? (p.ups ? ((t_b * p.H1 + (y >> 1)) * p.W1 + (x >> 1)) : ((t_b * p.H + y) * p.W + x)) * p.C1 * ES + sc16 : FAR;
+        h_o2[jj] = (ok && p.C2) ? ((t_b * p.H + y) * p.W + x) * p.C2 * ES + sc16 : FAR;
     }
     int b_o[BG];
 #pragma unroll
     for (int j = 0; j < BG; ++j) {
         const int g = wid * BG + j;
         const int n = n0 + 8 * g + (lane >> 3);
-        b_o[j] = n < p.Cout ? (n * p.K + 8 * ((lane & 7) ^ ((4 * g + (lane >> 4)) & 7))) * 2 : FAR;
+        b_o[j] = n < p.Cout ? n * p.K * ES + 16 * ((lane & 7) ^ ((4 * g + (lane >> 4)) & 7)) : FAR;
     }
-    const int Cin2 = (p.C1 + p.C2) * 2;
+    const int Cin2 = (p.C1 + p.C2) * ES;
     const int nch = (p.C1 + p.C2) / KT, nkt = nch * 9;
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -396,13 +397,13 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
         int off = 0;
 #pragma unroll
         for (int q = 0; q < PPW; ++q) if (q == jj) off = c0 < p.C1 ? h_o1[q] : h_o2[q];      // (static register names)
-        if (c0 < p.C1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, off + c0 * 2, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr)dst, 16, off + (c0 - p.C1) * 2, 0, 0, 0);
+        if (c0 < p.C1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, off + c0 * ES, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr)dst, 16, off + (c0 - p.C1) * ES, 0, 0, 0);
         return 1;
     };
     auto issue_b = [&](const int stage, const int c, const int tap, const bool live) {
         char* dst = bring + stage * BST + wid * (BG * 1024);
-        const int koff = live ? tap * Cin2 + c * (KT * 2) : FAR;
+        const int koff = live ? tap * Cin2 + c * 128 : FAR;
 #pragma unroll
         for (int j = 0; j < BG; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + j * 1024), 16, b_o[j] + koff, 0, 0, 0);
     };
@@ -450,7 +451,17 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = LowPrec<PREC>::mfma(a[qq & 1][i], b[qq & 1][j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (PREC != 0) {
+                            acc[i][j] = LowPrec<PREC>::mfma(a[qq & 1][i], b[qq & 1][j], acc[i][j]);
+                        } else {
+                            // fp32 (v_mfma_f32_32x32x2_f32): lane half lh read chunk 2 q + lh; element t of both operands is
+                            // k = 4 (2 q + lh) + t, so the four MFMAs of a chunk pair cover its 8 k-values
+#pragma unroll
+                            for (int t4 = 0; t4 < 4; ++t4)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[qq & 1][i][t4], b[qq & 1][j][t4], acc[i][j], 0, 0, 0);
+                        }
+                    }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -554,30 +565,47 @@ template <int BN, int WM, int WN, int NS, int PREC, int SUP = 1, int TH = 8, int
 __global__ __launch_bounds__(512, 2) void conv16h_kernel(ConvParams p) {
     conv16h_body<BN, WM, WN, NS, PREC, SUP, TH, PB>(p);
 }
+// fp32 tensors (PREC 0: rows of 32 channels): the same kernel on v_mfma_f32_32x32x2_f32
+static bool conv32h_applicable(const ConvParams& p) {
+    if (g_conv16_mode == 0 || p.io != 0) return false;
+    if (p.C1 % 32 || p.C2 % 32 || p.Cout % 8) return false;
+    const bool omap = p.osh != 1 || p.osw != 1 || p.ooh != 0 || p.oow != 0 || p.oH != p.Ho || p.oW != p.Wo;
+    return !(omap || !p.qepi || (p.y2 != nullptr && p.nsplit1 % 4));
+}
 // applicability of the patch-resident kernel; 0 or the N tile
-static int conv16h_tile(const ConvParams& p) {
-    if (!conv16_applicable(p)) return 0;
+// share of the last round of blocks that is filled on 256 CUs (one block per CU): 384 blocks = 1.5 rounds -> 0.75
+static double conv16h_tail(long blocks) {
+    if (blocks <= 0) return 0.0;
+    const long rounds = (blocks + 255) / 256;
+    return (double)blocks / (double)(rounds * 256);
+}
+static bool conv16h_grid_ok(long blocks) { return g_conv16_mode == 2 || (blocks >= 192 && conv16h_tail(blocks) >= 0.8); }
+static int conv16h_tile(const ConvParams& p, bool fp32 = false) {
+    if (!(fp32 ? conv32h_applicable(p) : conv16_applicable(p))) return 0;
     static const int hmode = ab_int("MMSEG_CONV16H", 1);     // measurement builds: 0 = never
     if (!hmode) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1 || p.Ho != p.H || p.Wo != p.W) return 0;
     if (p.W % 32 || p.H % 8) return 0;
     const int bn = p.Cout > 128 ? 256 : (p.Cout > 64 ? 128 : 64);
+    const long ntn = (p.Cout + bn - 1) / bn;
+    // mode 1: where it measured faster than conv_fast_kernel (tools/conv16_bench.py, DTYPE=f32 for the fp32 instances): grids that fill
+    // their last round of blocks; in fp32 more than 32 output channels (a 64-wide tile on 32 channels multiplies half of it by zero:
+    // 0.63 x in fp32, still 1.16 x in bf16 where the alternative is further from its roofline)
+    if (g_conv16_mode != 2 && fp32 && p.Cout <= 32) return 0;
     if (bn == 64) {                                          // 16 image rows per block (the 64-channel form)
         static const int h64 = ab_int("MMSEG_CONV16H_N64", 1);
         if (!h64 || p.H % 16) return 0;
-        if (g_conv16_mode != 2 && (long)(p.M / 512) < 192) return 0;
-        return 64;
+        return conv16h_grid_ok((long)(p.M / 512)) ? 64 : 0;
     }
-    if (g_conv16_mode != 2 && (long)(p.M / 256) * ((p.Cout + bn - 1) / bn) < 192) return 0;
-    return bn;
+    if (bn == 128 && p.H % 16 == 0 && conv16h_grid_ok((long)(p.M / 512) * ntn)) return bn;
+    return conv16h_grid_ok((long)(p.M / 256) * ntn) ? bn : 0;
 }
 // image rows per block of the patch-resident kernel for this launch: 16 for the 64-channel form; for 128 channels 16 where the image
 // and the grid allow (a wave then owns 4 rows x 64 channels = 128 x 64 outputs, 6 fragment reads per 8 MFMAs and 32 MFMAs between two
 // barriers: 1.17 - 1.21 x the 8-row form, tools/ab_th16.sh), else 8
 static int conv16h_rows(const ConvParams& p, int bn) {
     if (bn == 64) return 16;
-    if (bn == 128 && p.H % 16 == 0 && ab_int("MMSEG_CONV16H_TH16", 1) &&
-        (g_conv16_mode == 2 || (long)(p.M / 512) * ((p.Cout + 127) / 128) >= 192)) return 16;
+    if (bn == 128 && p.H % 16 == 0 && ab_int("MMSEG_CONV16H_TH16", 1) && conv16h_grid_ok((long)(p.M / 512) * ((p.Cout + 127) / 128))) return 16;
     return 8;
 }
 template <int PREC>
@@ -593,6 +621,10 @@ static int launch_conv16h_prec(const ConvParams& p, int bn, hipStream_t st) {
     else if (bn == 128 && conv16h_rows(p, bn) == 16)
         hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC, 1, 16, 1>), dim3((p.M / 512) * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
     else if (bn == 128) hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
+#ifdef MMSEG_AB
+    else if (ab_int("MMSEG_CONV16H_N64_TH8", 0))        // measurement builds: 8 rows, two patch buffers, wave tile 64 x 32
+        hipLaunchKernelGGL((conv16h_kernel<64, 4, 2, 3, PREC>), dim3(ntm), dim3(512), 0, st, p);
+#endif
     else hipLaunchKernelGGL((conv16h_kernel<64, 8, 1, 3, PREC, 1, 16, 1>), dim3(p.M / 512), dim3(512), 0, st, p);
     return MMSEG_CHECK_LAUNCH();
 }

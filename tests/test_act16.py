@@ -425,3 +425,52 @@ def test_large_tile_16bit_kernel_split_output_and_scale(mode):
             assert float((a.float() - c.float()).abs().max()) <= 2.0 ** -7 * float(a.float().abs().max())
     finally:
         N.call('mmseg_conv16_mode', prev)
+
+
+@pytest.mark.parametrize('B,H,W,C1,C2,Cout,ups,act', [
+    (2, 32, 64, 64, 0, 64, 0, 1),           # 64-channel form (16 rows per block, single patch buffer, two 32-channel chunks)
+    (1, 16, 32, 32, 0, 128, 0, 0),          # 128 channels, 16 rows
+    (1, 24, 64, 64, 0, 256, 0, 1),          # 256 channels, 8 rows, 3 x 2 tiles
+    (2, 16, 32, 64, 0, 64, 1, 1),           # up-sampled input
+    (1, 16, 64, 32, 64, 64, 0, 0),          # concatenation: one chunk of x1, two of x2
+    (1, 32, 32, 96, 0, 320, 0, 0),          # three chunks, Cout beyond one N tile
+    (1, 16, 32, 64, 32, 56, 0, 2),          # Cout = 56, LeakyReLU
+    (3, 8, 32, 32, 0, 128, 0, 0),           # 8-row image: the 8-row form of the 128-channel tile
+])
+def test_fp32_patch_resident_kernel(B, H, W, C1, C2, Cout, ups, act):
+    """conv16h_kernel<..., PREC 0, ...> (round 4: the patch-resident large-tile kernel on v_mfma_f32_32x32x2_f32, rows of 32 fp32
+    channels) forced onto small problems against conv_fast_kernel and against the fp64 oracle: fp32 products, fp32 accumulation,
+    another association of the sums"""
+    from oracle import ops as O
+    prevp = P.set_conv_precision('fp32')
+    prev = N.call('mmseg_conv16_mode', 0)
+    try:
+        H1, W1 = (H // 2, W // 2) if ups else (H, W)
+        x1 = rnd(B, H1, W1, C1, seed=1).to(DEV)
+        x2 = rnd(B, H, W, C2, seed=2).to(DEV) if C2 else None
+        Cin = C1 + C2
+        w = (rnd(3, 3, Cin, Cout, seed=3) * (2.0 / (9 * Cin)) ** 0.5).to(DEV)
+        b = rnd(Cout, seed=4).to(DEV)
+        wp = torch.empty(w.numel(), device=DEV)
+        N.call('mmseg_conv2d_wprep', w, wp, 3, 3, Cin, Cout, 0)
+        outs = {}
+        for m16 in (0, 2):
+            N.call('mmseg_conv16_mode', m16)
+            y = torch.full((B, H, W, Cout), float('nan'), device=DEV)
+            N.call('mmseg_conv2d_fwd', x1, x2, w, wp, b, y, None, B, H, W, C1, C2, H, W, Cout, 3, 3, 1, 1, 1, ups, 0, act, 0.2, 0)
+            outs[m16] = y
+            assert N.call('mmseg_conv2d_last_kernel') // 1000000 == (17 if m16 == 2 else 1)
+        a = x1.cpu().double()
+        if ups:
+            a = O.upsample2(a)
+        if C2:
+            a = torch.cat([a, x2.cpu().double()], -1)
+        ref = O.conv2d(a, w.cpu().double(), b.cpu().double())
+        ref = torch.relu(ref) if act == 1 else (O.leaky_relu(ref, 0.2) if act == 2 else ref)
+        scale = float(ref.abs().max())
+        assert not torch.isnan(outs[2]).any()
+        assert float((outs[2].cpu().double() - ref).abs().max()) <= 5e-6 * scale
+        assert float((outs[2] - outs[0]).abs().max()) <= 5e-6 * scale
+    finally:
+        N.call('mmseg_conv16_mode', prev)
+        P.set_conv_precision(prevp)

@@ -31,8 +31,9 @@ def timeit(fn, iters):
 
 
 def main():
-    dt = torch.bfloat16
-    P.set_conv_precision('bf16')
+    f32 = os.environ.get('DTYPE') == 'f32'          # DTYPE=f32: the fp32 instances of the patch-resident kernel vs conv_fast_kernel (fp32 MFMA)
+    dt = torch.float32 if f32 else torch.bfloat16
+    P.set_conv_precision('fp32' if f32 else 'bf16')
     dev = torch.device('cuda')
     only = os.environ.get('ONLY')
     print('%-34s %9s %9s %7s %7s' % ('B,H,C1,C2,Cout,k,ups', 'fast TF', 'conv16 TF', 'frac', 'speedup'))
@@ -50,7 +51,10 @@ def main():
         y = torch.empty(B, H, H, Cout, device=dev, dtype=dt)
         p = k // 2
         io = 1 | (2 if C2 else 0) | 4
-        fn = lambda: N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, p, p, ups, 0, 1, 0.0, 0, io)
+        if f32:
+            fn = lambda: N.call('mmseg_conv2d_fwd', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, p, p, ups, 0, 1, 0.0, 0)
+        else:
+            fn = lambda: N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, p, p, ups, 0, 1, 0.0, 0, io)
         flops = 2.0 * B * H * H * Cin * Cout * k * k
         res = {0: [], 2: []}
         for m in (0, 2):
@@ -66,7 +70,7 @@ def main():
         fam = N.call('mmseg_conv2d_last_kernel')
         t0, t2 = min(res[0]), min(res[2])
         print('%-34s %9.1f %9.1f %7.3f %7.2fx   auto->%d' % (str((B, H, C1, C2, Cout, k, ups)), flops / t0 / 1e9, flops / t2 / 1e9,
-                                                         flops / t2 / 1e9 / 2500.0, t0 / t2, fam))
+                                                         flops / t2 / 1e9 / (157.3 if f32 else 2500.0), t0 / t2, fam))
 
 
 if __name__ == '__main__':

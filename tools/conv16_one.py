@@ -11,8 +11,9 @@ from multimodal_segmentation_amd import _native as N, ops as P
 
 mode, B, H, C1, C2, Cout, k, ups = [int(v) for v in sys.argv[1:9]]
 iters = int(sys.argv[9]) if len(sys.argv) > 9 else 20
-dt = torch.bfloat16
-P.set_conv_precision('bf16')
+f32 = os.environ.get('DTYPE') == 'f32'
+dt = torch.float32 if f32 else torch.bfloat16
+P.set_conv_precision('fp32' if f32 else 'bf16')
 dev = torch.device('cuda')
 H1 = H // 2 if ups else H
 x1 = torch.randn(B, H1, H1, C1, device=dev).to(dt)
@@ -25,12 +26,12 @@ N.call('mmseg_conv2d_wprep', w, wp, k, k, Cin, Cout, 0)
 y = torch.empty(B, H, H, Cout, device=dev, dtype=dt)
 N.call('mmseg_conv16_mode', mode)
 for _ in range(3):
-    N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, k // 2, k // 2, ups, 0, 1, 0.0, 0, 1 | (2 if C2 else 0) | 4)
+    (N.call('mmseg_conv2d_fwd', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, k // 2, k // 2, ups, 0, 1, 0.0, 0) if f32 else N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, k // 2, k // 2, ups, 0, 1, 0.0, 0, 1 | (2 if C2 else 0) | 4))
 torch.cuda.synchronize()
 _s, _e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 _s.record()
 for _ in range(iters):
-    N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, k // 2, k // 2, ups, 0, 1, 0.0, 0, 1 | (2 if C2 else 0) | 4)
+    (N.call('mmseg_conv2d_fwd', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, k // 2, k // 2, ups, 0, 1, 0.0, 0) if f32 else N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, H, C1, C2, H, H, Cout, k, k, 1, k // 2, k // 2, ups, 0, 1, 0.0, 0, 1 | (2 if C2 else 0) | 4))
 _e.record()
 torch.cuda.synchronize()
 ms = _s.elapsed_time(_e) / iters
