@@ -26,6 +26,7 @@ LINES = [('bench_f32', 'python bench.py --steps 20 --warmup 5 (headline: DAFNet-
          ('bench_spade_bf16_act16_onestream', '--decoder spade --dtype bf16 --act16 --no-multi-stream'),
          ('bench_mmsdnet3_320_f16_act16', '--model mmsdnet --modalities 3 --size 320 --batch 16 --dtype f16 --act16 (BASELINE config #5 model, per GPU)'),
          ('bench_spade_bf16_act16_conv16off', '--decoder spade --dtype bf16 --act16 --conv16 0 (the round-3 16-bit kernels only)'),
+         ('bench_f32_conv16off', '--conv16 0 (fp32 headline workload on the round-3 kernels only)'),
          ('bench_lmix01', '--l_mix 0.1 (BASELINE config #4 schedule, per GPU)')]
 
 
@@ -53,7 +54,7 @@ def main():
     for src, dst in (('final_kernel_stats.txt', 'r04_final_kernel_stats_bench_dafnet_film_256_bs8.txt'),
                      ('kernel_stats_spade_bf16_act16.txt', 'r04_kernel_stats_bench_dafnet_spade_256_bs8_bf16_act16.txt'),
                      ('gpu_busy.txt', 'r04_gpu_busy_bench_dafnet_film_256_bs8.txt'), ('conv_traffic.json', 'r04_conv_traffic.json'),
-                     ('conv16_ab.txt', 'r04_conv16_ab.txt')):
+                     ('conv16_ab.txt', 'r04_conv16_ab.txt'), ('conv16_ab_f32.txt', 'r04_conv16_ab_f32.txt')):
         if os.path.exists(os.path.join(EV, src)):
             shutil.copy(os.path.join(EV, src), os.path.join(P, dst))
 

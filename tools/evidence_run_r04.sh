@@ -19,6 +19,8 @@ python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --decoder spade --dt
 python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --model mmsdnet --modalities 3 --size 320 --batch 16 --dtype f16 --act16 > $O/bench_mmsdnet3_320_f16_act16.json 2> $O/bench_mmsdnet3_320_f16_act16.err
 python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --l_mix 0.1 > $O/bench_lmix01.json 2> $O/bench_lmix01.err
 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --decoder spade --dtype bf16 --act16 --conv16 0 > $O/bench_spade_bf16_act16_conv16off.json 2> $O/bench_spade_bf16_act16_conv16off.err
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --conv16 0 > $O/bench_f32_conv16off.json 2> $O/bench_f32_conv16off.err
+DTYPE=f32 timeout -k 10 400 python3 $R/tools/conv16_bench.py > $O/conv16_ab_f32.txt 2>&1
 timeout -k 10 400 python3 $R/tools/conv16_bench.py > $O/conv16_ab.txt 2>&1
 echo benches done
 cd $R
