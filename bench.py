@@ -51,6 +51,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
 def kernel_name(kid, prec):
     """mmseg_conv2d_last_kernel() id -> the kernel name rocprofv3 reports (template arguments included)"""
     fam, rest = kid // 1000000, kid % 1000000
+    if fam == 18:              # <input-channel planes, output-channel planes> of the patch-resident fp32 weight gradient
+        return 'wgrad32h_kernel<%d, %d>' % (rest // 1000, rest % 1000)
     if fam in (16, 17):        # the large-tile 16-bit kernels: plain <pixels per block> * 1000 + <N tile> (no flag fields)
         bm, bn = rest // 1000, rest % 1000
         if fam == 16:          # <M tile, N tile, waves M, waves N, ring stages, precision>

@@ -781,7 +781,7 @@ static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
 // M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / 16-bit input of the fast kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
 // 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel,
 // 10 pw_reduce_kernel<LANES, COUT, VPL>, 12 pw_reduce_wgrad_kernel<...> (M tile field = LANES, N tile field = COUT);
-// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv_wgrad_tr_anyw_kernel; 16 conv16_kernel, 17 conv16h_kernel (M tile field = pixels per block)
+// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv_wgrad_tr_anyw_kernel; 16 conv16_kernel, 17 conv16h_kernel (M tile field = pixels per block), 18 wgrad32h_kernel<NCI, NCO>
 static int g_last_kernel = 0;
 #define MMSEG_SET_LAST(fam, bm, bn) (g_last_kernel = (fam) * 1000000 + (bm) * 1000 + (bn))
 template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false>
@@ -2188,6 +2188,8 @@ __global__ void wprep_parity_all_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+#include "wgrad32h.hpp"
+
 extern "C" {
 // large-tile 16-bit kernel (conv16.hpp): 0 off, 1 where it pays (default), 2 wherever it applies; returns the previous mode
 int mmseg_conv16_mode(int mode) {
@@ -2406,6 +2408,15 @@ long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int 
         const long need_tr = wgrad_ws_floats(wgrad_tr_splits(M, K, Cout, nullptr), K * Cout);
         if (need_tr > need) need = need_tr;
     }
+    if (KH == 3 && KW == 3 && Wo % 32 == 0 && Cin % 32 == 0 && Cout % 32 == 0) {
+        // the patch-resident fp32 kernel (wgrad32h.hpp) may take this geometry: at most 512 slabs
+        const long ntiles = (long)B * (Ho / 2) * (Wo / 32);
+        long Sh = 512;
+        if (Sh > ntiles / 8) Sh = ntiles / 8;
+        if (Sh < 1) Sh = 1;
+        const long need_h = wgrad_ws_floats(Sh, K * Cout);
+        if (need_h > need) need = need_h;
+    }
     return need;
 }
 
@@ -2476,6 +2487,26 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
     const bool direct = S == 1 && !accumulate;      // a single slab that overwrites dW needs no staging
     q.dy = dy; q.chunk = chunk; q.ws = direct ? dw : ws;
     hipStream_t st = (hipStream_t)stream;
+    if (fast && aligned16(x1) && (C2 == 0 || aligned16(x2))) {
+        // fp32, 3x3 'same', channel counts multiples of 32, rows of 32 pixels: the patch-resident kernel (wgrad32h.hpp)
+        int Sh = 0, tpb = 0;
+        const int nci = wgrad32h_plan(p, &Sh, &tpb);
+        if (nci && wgrad_ws_floats(Sh, KN) <= ws_floats) {
+            const bool directh = Sh == 1 && !accumulate;
+            q.ws = directh ? dw : ws;
+            const int Cin = C1 + C2, nco = 4 / nci;
+            const unsigned grid = (unsigned)((Cin / (32 * nci)) * ((Cout + 32 * nco - 1) / (32 * nco)) * Sh);
+            if (nci == 1) hipLaunchKernelGGL((wgrad32h_kernel<1, 4>), dim3(grid), dim3(768), 0, st, q, tpb);
+            else if (nci == 2) hipLaunchKernelGGL((wgrad32h_kernel<2, 2>), dim3(grid), dim3(768), 0, st, q, tpb);
+            else hipLaunchKernelGGL((wgrad32h_kernel<4, 1>), dim3(grid), dim3(768), 0, st, q, tpb);
+            MMSEG_SET_LAST(18, nci, 4 / nci);
+            const int rc = MMSEG_CHECK_LAUNCH();
+            if (rc != 0 || directh) return rc;
+            launch_slab_reduce(ws, (Sh > 64) ? ws + (size_t)Sh * KN : nullptr, dw, KN, Sh, accumulate, st);
+            return MMSEG_CHECK_LAUNCH();
+        }
+        q.ws = direct ? dw : ws;
+    }
     if (C1 == 8 && C2 == 0 && Cout == 8 && KH == 3 && KW == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && !ups && Ho == H &&
         Wo == W && H % WG8_ROWS == 0 && W % WG8_COLS == 0 && S > 1 && aligned16(x1) && aligned16(dy)) {
         const int ntiles = B * (H / WG8_ROWS) * (W / WG8_COLS);

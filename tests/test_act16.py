@@ -474,3 +474,56 @@ def test_fp32_patch_resident_kernel(B, H, W, C1, C2, Cout, ups, act):
     finally:
         N.call('mmseg_conv16_mode', prev)
         P.set_conv_precision(prevp)
+
+
+@pytest.mark.parametrize('B,H,W,C1,C2,Cout,ups,acc', [
+    (2, 8, 32, 32, 0, 128, 0, 0),           # <1, 4>: one input-channel plane, four output-channel planes
+    (1, 16, 64, 64, 0, 64, 0, 1),           # <2, 2>, accumulating into dW
+    (2, 6, 32, 128, 0, 32, 0, 0),           # <4, 1>
+    (1, 8, 64, 64, 64, 64, 0, 0),           # concatenated inputs: planes walk x1, then x2
+    (2, 8, 32, 64, 0, 128, 1, 1),           # up-sampled x1 (stored 4 x 16)
+    (3, 4, 32, 96, 0, 256, 0, 0),           # three input planes, two output tiles, batch 3
+])
+def test_fp32_patch_resident_weight_gradient(B, H, W, C1, C2, Cout, ups, acc):
+    """wgrad32h_kernel (round 4: the 3x3 weight gradient with the activation patch and the dy tile resident in LDS, operands read as
+    they lie -- no transposition on the fp32 MFMA) forced onto small problems (mmseg_conv16_mode 2) against conv_wgrad_tr_kernel
+    (mode 0) and against the fp64 oracle's autograd"""
+    from oracle import ops as O
+    prevp = P.set_conv_precision('fp32')
+    prev = N.call('mmseg_conv16_mode', 0)
+    try:
+        H1, W1 = (H // 2, W // 2) if ups else (H, W)
+        x1 = rnd(B, H1, W1, C1, seed=1).to(DEV)
+        x2 = rnd(B, H, W, C2, seed=2).to(DEV) if C2 else None
+        dy = rnd(B, H, W, Cout, seed=3).to(DEV)
+        Cin = C1 + C2
+        base = (rnd(3, 3, Cin, Cout, seed=4) * 0.1).to(DEV)
+        need = N.call('mmseg_conv2d_wgrad_workspace', B, H, W, Cin, Cout, 3, 3)
+        ws = torch.full((max(need, 1),), float('nan'), device=DEV)
+        outs = {}
+        for m16 in (0, 2):
+            N.call('mmseg_conv16_mode', m16)
+            dw = base.clone() if acc else torch.full_like(base, float('nan'))
+            N.call('mmseg_conv2d_wgrad', x1, x2, dy, dw.view(-1), ws, ws.numel(), B, H, W, C1, C2, H, W, Cout, 3, 3, 1, 1, 1, ups, acc)
+            outs[m16] = dw
+            fam = N.call('mmseg_conv2d_last_kernel') // 1000000
+            assert (fam == 18) == (m16 == 2), 'launch went to kernel family %d' % fam
+        a = x1.cpu().double()
+        if ups:
+            a = O.upsample2(a)
+        if C2:
+            a = torch.cat([a, x2.cpu().double()], -1)
+        wref = torch.zeros(3, 3, Cin, Cout, dtype=torch.float64, requires_grad=True)
+        O.conv2d(a, wref, None).backward(dy.cpu().double())
+        ref = wref.grad + (base.cpu().double() if acc else 0.0)
+        scale = float(ref.abs().max())
+        assert not torch.isnan(outs[2]).any()
+        assert float((outs[2].cpu().double() - ref).abs().max()) <= 2e-5 * scale
+        assert float((outs[2] - outs[0]).abs().max()) <= 2e-5 * scale
+        # bitwise reproducible: fixed tile order per block, fixed-order slab reduction
+        dw2 = base.clone() if acc else torch.full_like(base, float('nan'))
+        N.call('mmseg_conv2d_wgrad', x1, x2, dy, dw2.view(-1), ws, ws.numel(), B, H, W, C1, C2, H, W, Cout, 3, 3, 1, 1, 1, ups, acc)
+        assert torch.equal(dw2, outs[2])
+    finally:
+        N.call('mmseg_conv16_mode', prev)
+        P.set_conv_precision(prevp)

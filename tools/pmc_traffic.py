@@ -30,7 +30,7 @@ def family(k):
     if k.startswith(('conv16h_kernel', 'conv16_kernel', 'conv_fast_kernel', 'conv_fast_batched_kernel', 'conv_fwd_kernel', 'conv_direct_kernel', 'conv_direct_mfma_kernel', 'conv_dgrad', 'pw_reduce_kernel',
                      'smallk_conv_kernel', 'tapsum_kernel')):
         return 'conv_fwd'
-    if k.startswith(('conv_wgrad', 'slab_reduce', 'pw_reduce_wgrad_kernel', 'smallk_wgrad_kernel')):
+    if k.startswith(('wgrad32h_kernel', 'conv_wgrad', 'slab_reduce', 'pw_reduce_wgrad_kernel', 'smallk_wgrad_kernel')):
         return 'conv_wgrad'
     return None
 
