@@ -49,6 +49,17 @@ def main():
                 m = re.search(r'= ([0-9.]+) % GPU-busy', open(busy).read())
                 if m:
                     d['from_committed_profile']['gpu_busy_frac']['value'] = float(m.group(1)) / 100.0
+            # ... and the HBM bytes per launch from this session's PMC passes (bench.py read the previous session's file)
+            tj = os.path.join(EV, 'conv_traffic.json')
+            if name == 'bench_f32' and os.path.exists(tj):
+                tw = json.load(open(tj)).get('workloads', {}).get('dafnet-film-256-bs8-f32-lmix1', {})
+                kern, fams = tw.get('kernels', {}), tw.get('families', {})
+                for e in [d.get('roofline', {})] + d.get('roofline_kernels', []):
+                    if e.get('kernel') in kern:
+                        e['traffic'] = kern[e['kernel']]['hbm_bytes_per_launch']
+                for k, fk in (('conv_fwd_kernel', 'conv_fwd'), ('conv_wgrad_kernel', 'conv_wgrad')):
+                    if k in d.get('roofline_family', {}) and fk in fams:
+                        d['roofline_family'][k]['traffic'] = fams[fk]['hbm_bytes_per_launch']
             out.write(json.dumps(d) + '\n')
             print('%-36s %8.2f slices/s  %8.2f ms' % (name, d['value'], d['ms_per_step']))
     for src, dst in (('final_kernel_stats.txt', 'r04_final_kernel_stats_bench_dafnet_film_256_bs8.txt'),
