@@ -781,7 +781,7 @@ static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
 // M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / 16-bit input of the fast kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
 // 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel,
 // 10 pw_reduce_kernel<LANES, COUT, VPL>, 12 pw_reduce_wgrad_kernel<...> (M tile field = LANES, N tile field = COUT);
-// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv_wgrad_tr_anyw_kernel; 16 conv16_kernel, 17 conv16h_kernel (M tile field = pixels per block), 18 wgrad32h_kernel<NCI, NCO>
+// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv_wgrad_tr_anyw_kernel; 16 conv16_kernel, 17 conv16h_kernel (M tile field = pixels per block), 18 wgrad32h_kernel<NCI, NCO>, 19 wgrad16h_kernel
 static int g_last_kernel = 0;
 #define MMSEG_SET_LAST(fam, bm, bn) (g_last_kernel = (fam) * 1000000 + (bm) * 1000 + (bn))
 template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false>
@@ -2500,6 +2500,20 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
             else if (nci == 2) hipLaunchKernelGGL((wgrad32h_kernel<2, 2>), dim3(grid), dim3(768), 0, st, q, tpb);
             else hipLaunchKernelGGL((wgrad32h_kernel<4, 1>), dim3(grid), dim3(768), 0, st, q, tpb);
             MMSEG_SET_LAST(18, nci, 4 / nci);
+            const int rc = MMSEG_CHECK_LAUNCH();
+            if (rc != 0 || directh) return rc;
+            launch_slab_reduce(ws, (Sh > 64) ? ws + (size_t)Sh * KN : nullptr, dw, KN, Sh, accumulate, st);
+            return MMSEG_CHECK_LAUNCH();
+        }
+        q.ws = direct ? dw : ws;
+        // ... and its 16-bit form (operands through ds_read_b64_tr_b16)
+        if (wgrad16h_plan(p, &Sh, &tpb) && wgrad_ws_floats(Sh, KN) <= ws_floats) {
+            const bool directh = Sh == 1 && !accumulate;
+            q.ws = directh ? dw : ws;
+            const unsigned grid = (unsigned)(((C1 + C2) / 64) * (Cout / 64) * Sh);
+            if (g_conv_bf16 == 1) hipLaunchKernelGGL((wgrad16h_kernel<1>), dim3(grid), dim3(768), 0, st, q, tpb);
+            else hipLaunchKernelGGL((wgrad16h_kernel<2>), dim3(grid), dim3(768), 0, st, q, tpb);
+            MMSEG_SET_LAST(19, 64, 64);
             const int rc = MMSEG_CHECK_LAUNCH();
             if (rc != 0 || directh) return rc;
             launch_slab_reduce(ws, (Sh > 64) ? ws + (size_t)Sh * KN : nullptr, dw, KN, Sh, accumulate, st);

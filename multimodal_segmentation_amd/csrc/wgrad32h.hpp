@@ -203,3 +203,171 @@ static int wgrad32h_plan(const ConvParams& p, int* S_out, int* tpb_out) {
     *S_out = (int)S; *tpb_out = (int)tpb;
     return nci;
 }
+
+// =====================================================================================================================================
+// wgrad16h: the same weight gradient for 16-bit tensors (bf16 / fp16 operands on v_mfma_f32_32x32x16_*, fp32 accumulation and slabs).
+// Here the MFMA's K index holds 16 PIXELS and a lane's operand is 8 consecutive pixels of ONE channel -- a column of the [pixel][channel]
+// image in LDS.  gfx950's ds_read_b64_tr_b16 delivers exactly that: per group of 16 lanes it reads 4 rows (pixels) x 16 columns (channels)
+// and hands lane i column i; lane 4 q + p of the group supplies the address of row q, columns 4 p .. 4 p + 3 (checked element by element on
+// the hardware before this kernel was written).  Two such reads give a lane its 8 pixels; the image stays as buffer_load ... lds wrote it.
+//   * block = 64 input channels x 64 output channels (one 128-byte-row plane each) and a share of the image's pixel tiles (8 rows x 32
+//     columns); 12 waves = (input half, output half, kernel row), three 32 x 32 tap accumulators per wave for the whole launch;
+//   * per tile the 10 x 34-pixel activation patch (43 KB) and the 256-pixel dy tile (32 KB) arrive by LDS-DMA, double buffered (152 KB);
+//   * swizzle: 16-byte chunk position = chunk ^ 4 ((pixel >> 1) & 1): the four pixels of a transposed read then cover both halves of
+//     the 256-byte bank row without meeting (pixels p and p + 2 use chunk sets 4 a .. 4 a + 3 and its complement);
+//   * every operand address is a per-lane constant per (kernel column, row parity) plus an IMMEDIATE: the tile loop is straight-line
+//     code with no address arithmetic (three copies, one per kernel row).
+template <int PREC>
+__device__ __forceinline__ void wgrad16h_body(const WgradParams& q, const int tpb) {
+    constexpr int NW = 12, TH = 8;
+    constexpr int XPIX = (TH + 2) * 34, XPC = (XPIX + 7) / 8, XP = XPC * 1024;      // 340 pixels -> 43 pieces
+    constexpr int DPIX = TH * 32, DPC = DPIX / 8, DT = DPIX * 128;                  // 256 pixels -> 32 pieces
+    constexpr int NPC = XPC + DPC, PPW = (NPC + NW - 1) / NW;                       // 75 pieces, 7 per wave
+    constexpr int SS = XP + DT;
+    static_assert(2 * SS <= 160 * 1024, "LDS");
+    typedef typename LowPrec<PREC>::V8 LV8;
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    const ConvParams& p = q.c;
+
+    __shared__ __attribute__((aligned(1024))) char smem[2 * SS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int kh = wid % 3, pl = wid / 3;
+    const int ha = pl >> 1, hb = pl & 1;                                  // this wave's 32-channel half of the input / output plane
+    const int Cin = p.C1 + p.C2;
+    const int ncb = Cin / 64, nnb = p.Cout / 64;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = bid % ncb, nb = (bid / ncb) % nnb, s = bid / (ncb * nnb);
+    const int tw = p.W / 32, th = p.H / TH, tpi = tw * th, ntiles = p.B * tpi;
+    const int t0 = s * tpb, t1 = min(ntiles, t0 + tpb);
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
+                                                                        p.C2 ? p.B * p.H * p.W * p.C2 * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)q.dy, 0, p.M * p.Cout * 2, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    constexpr int FAR = 0x40000000;
+
+    auto issue_tile = [&](const int t, const int stage) {
+        char* base = smem + stage * SS;
+        const int b = t / tpi, tr = t - b * tpi;
+        const int tx = tr / th, ty = tr - tx * th;                        // down a 32-pixel column strip (wgrad32h)
+        const int c0 = cb * 64;
+#pragma unroll
+        for (int jj = 0; jj < PPW; ++jj) {
+            const int id = jj * NW + wid;
+            if (id >= NPC) break;
+            if (id < XPC) {
+                const int pix = 8 * id + (lane >> 3);
+                const int sc16 = 16 * ((lane & 7) ^ (4 * ((pix >> 1) & 1)));
+                const int hy = pix / 34, hx = pix - hy * 34;
+                const int y = TH * ty - 1 + hy, x = 32 * tx - 1 + hx;
+                const bool ok = pix < XPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                if (c0 < p.C1) {
+                    const int pixoff = p.ups ? ((b * p.H1 + (y >> 1)) * p.W1 + (x >> 1)) : ((b * p.H + y) * p.W + x);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)(base + id * 1024), 16, ok ? (pixoff * p.C1 + c0) * 2 + sc16 : FAR, 0, 0, 0);
+                } else {
+                    const int pixoff = (b * p.H + y) * p.W + x;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr)(base + id * 1024), 16, ok ? (pixoff * p.C2 + (c0 - p.C1)) * 2 + sc16 : FAR, 0, 0, 0);
+                }
+            } else {
+                const int pp = id - XPC;
+                const int pix = 8 * pp + (lane >> 3);                     // row pix >> 5, column pix & 31 of the tile
+                const int sc16 = 16 * ((lane & 7) ^ (4 * ((pix >> 1) & 1)));
+                const int m = (b * p.H + TH * ty + (pix >> 5)) * p.W + 32 * tx + (pix & 31);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr)(base + XP + pp * 1024), 16, (m * p.Cout + nb * 64) * 2 + sc16, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kw][r] = 0.f;
+
+    // transposed-read addressing of this lane: group g = lane >> 4 (channels 16 (g & 1) + ., pixels 8 (g >> 1) + .), i = lane & 15 -> row q = i >> 2,
+    // columns 4 (i & 3) ..; chunk of the plane = 4 half + 2 (g & 1) + (p >> 1), 8 bytes into it for odd p
+    const int g = lane >> 4, qi = (lane >> 2) & 3, pi = lane & 3;
+    const int rowoff = (8 * (g >> 1) + qi) * 128 + 8 * (pi & 1);
+    const int chA = 4 * ha + 2 * (g & 1) + (pi >> 1), chB = 4 * hb + 2 * (g & 1) + (pi >> 1);
+    // key of pixel P = (patch row) * 34 + 16 blk + kw + 8 h + 4 rd + q is 4 ((row * 17 + ((kw + q) >> 1)) & 1): per (kw, row parity) a lane constant
+    int offA[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) offA[kw][par] = rowoff + 16 * (chA ^ (4 * ((par + ((kw + qi) >> 1)) & 1)));
+    const int offB = rowoff + 16 * (chB ^ (4 * ((qi >> 1) & 1))) + XP;
+
+    auto tr8 = [&](const int addr) -> LV8 {          // 8 pixels of this lane's channel: two transposed reads, 4 pixels (512 bytes of image) apart
+        const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(smem + addr));
+        const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(smem + addr + 4 * 128));
+        return __builtin_bit_cast(LV8, s8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+    };
+    auto mma_tile_kh = [&](const int stage, auto khc) {
+        constexpr int KHc = decltype(khc)::value;
+        const int sb = stage * SS;
+#pragma unroll
+        for (int r = 0; r < TH; ++r)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const LV8 bv = tr8(sb + offB + (r * 32 + 16 * blk) * 128);
+                LV8 av[3];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) av[kw] = tr8(sb + offA[kw][(r + KHc) & 1] + ((r + KHc) * 34 + 16 * blk + kw) * 128);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc[kw] = LowPrec<PREC>::mfma(av[kw], bv, acc[kw]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    auto mma_tile = [&](const int stage) {
+        if (kh == 0) mma_tile_kh(stage, std::integral_constant<int, 0>());
+        else if (kh == 1) mma_tile_kh(stage, std::integral_constant<int, 1>());
+        else mma_tile_kh(stage, std::integral_constant<int, 2>());
+    };
+
+    if (t0 < t1) {
+        issue_tile(t0, 0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int t = t0; t < t1; ++t) {
+            const int stage = (t - t0) & 1;
+            if (t + 1 < t1) issue_tile(t + 1, stage ^ 1);
+            mma_tile(stage);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+
+    float* slab = q.ws + (size_t)s * ((size_t)p.K * p.Cout);
+    const int co = nb * 64 + hb * 32 + li;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = cb * 64 + ha * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[((size_t)(kh * 3 + kw) * Cin + ci) * p.Cout + co] = acc[kw][r];
+        }
+}
+template <int PREC>
+__global__ __launch_bounds__(768, 3) void wgrad16h_kernel(WgradParams q, int tpb) {
+    wgrad16h_body<PREC>(q, tpb);
+}
+// plan of the 16-bit form: 1 if applicable (64-channel planes, 8-row tiles)
+static int wgrad16h_plan(const ConvParams& p, int* S_out, int* tpb_out) {
+    static const int on = ab_int("MMSEG_WGRAD16H", 1);
+    if (!on || g_conv_bf16 == 0 || (p.io & 5) != 5 || g_conv16_mode == 0) return 0;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1 || p.Ho != p.H || p.Wo != p.W) return 0;
+    if (p.W % 32 || p.H % 8 || p.C1 % 64 || p.C2 % 64 || p.Cout % 64) return 0;
+    const long nbk = (long)((p.C1 + p.C2) / 64) * (p.Cout / 64);
+    const long ntiles = (long)p.B * (p.H / 8) * (p.W / 32);
+    static const int target = ab_int("MMSEG_WGRAD16H_BLOCKS", 256);
+    long S = (target + nbk - 1) / nbk;
+    if (S > ntiles / 2) S = ntiles / 2;
+    if (S < 1) S = 1;
+    if (g_conv16_mode != 2 && nbk * S < 192) return 0;
+    long tpb = (ntiles + S - 1) / S;
+    S = (ntiles + tpb - 1) / tpb;
+    *S_out = (int)S; *tpb_out = (int)tpb;
+    return 1;
+}

@@ -527,3 +527,51 @@ def test_fp32_patch_resident_weight_gradient(B, H, W, C1, C2, Cout, ups, acc):
     finally:
         N.call('mmseg_conv16_mode', prev)
         P.set_conv_precision(prevp)
+
+
+@pytest.mark.parametrize('B,H,W,C1,C2,Cout,ups,acc', [
+    (2, 8, 32, 64, 0, 64, 0, 0),            # one tile per image: every patch border outside the image
+    (1, 16, 64, 64, 0, 128, 0, 1),          # 2 x 2 tiles, two output planes, accumulating
+    (2, 8, 32, 128, 0, 64, 1, 0),           # up-sampled x1, two input planes
+    (1, 24, 32, 64, 64, 64, 0, 0),          # concatenated inputs, three tiles down one column strip
+    (3, 8, 64, 192, 0, 128, 0, 1),          # three input planes, batch 3
+])
+def test_16bit_patch_resident_weight_gradient(B, H, W, C1, C2, Cout, ups, acc, mode):
+    """wgrad16h_kernel (round 4: operands through ds_read_b64_tr_b16 from the [pixel][channel] image in LDS) forced onto small problems
+    against conv_wgrad_tr_kernel's 16-bit instance (mode 0) and against the fp64 oracle on the 16-bit operands"""
+    from oracle import ops as O
+    prev = N.call('mmseg_conv16_mode', 0)
+    try:
+        H1, W1 = (H // 2, W // 2) if ups else (H, W)
+        x1 = rnd(B, H1, W1, C1, seed=1).to(mode).to(DEV)
+        x2 = rnd(B, H, W, C2, seed=2).to(mode).to(DEV) if C2 else None
+        dy = rnd(B, H, W, Cout, seed=3).to(mode).to(DEV)
+        Cin = C1 + C2
+        base = (rnd(3, 3, Cin, Cout, seed=4) * 0.1).to(DEV)
+        need = N.call('mmseg_conv2d_wgrad_workspace', B, H, W, Cin, Cout, 3, 3)
+        ws = torch.full((max(need, 1),), float('nan'), device=DEV)
+        outs = {}
+        for m16 in (0, 2):
+            N.call('mmseg_conv16_mode', m16)
+            dw = base.clone() if acc else torch.full_like(base, float('nan'))
+            N.call('mmseg_conv2d_wgrad_t', x1, x2, dy, dw.view(-1), ws, ws.numel(), B, H, W, C1, C2, H, W, Cout, 3, 3, 1, 1, 1, ups, acc, 5)
+            outs[m16] = dw
+            fam = N.call('mmseg_conv2d_last_kernel') // 1000000
+            assert (fam == 19) == (m16 == 2), 'launch went to kernel family %d' % fam
+        a = x1.float().cpu().double()
+        if ups:
+            a = O.upsample2(a)
+        if C2:
+            a = torch.cat([a, x2.float().cpu().double()], -1)
+        wref = torch.zeros(3, 3, Cin, Cout, dtype=torch.float64, requires_grad=True)
+        O.conv2d(a, wref, None).backward(dy.float().cpu().double())
+        ref = wref.grad + (base.cpu().double() if acc else 0.0)
+        scale = float(ref.abs().max())
+        assert not torch.isnan(outs[2]).any()
+        assert float((outs[2].cpu().double() - ref).abs().max()) <= 2e-5 * scale       # exact 16-bit products, fp32 sums
+        assert float((outs[2] - outs[0]).abs().max()) <= 2e-5 * scale
+        dw2 = base.clone() if acc else torch.full_like(base, float('nan'))
+        N.call('mmseg_conv2d_wgrad_t', x1, x2, dy, dw2.view(-1), ws, ws.numel(), B, H, W, C1, C2, H, W, Cout, 3, 3, 1, 1, 1, ups, acc, 5)
+        assert torch.equal(dw2, outs[2])
+    finally:
+        N.call('mmseg_conv16_mode', prev)
