@@ -1,3 +1,6 @@
+// Probe of ds_read_b64_tr_b16 (gfx950): hipcc --offload-arch=gfx950 -O2 tools/tr16_probe.hip -o /tmp/tr16_probe && /tmp/tr16_probe
+// Checks, element by element, that two transposed reads with the lane -> (row, columns) address rule of csrc/wgrad32h.hpp (wgrad16h) give every lane the 8 pixels
+// of ITS channel that v_mfma_f32_32x32x16_bf16 expects as the A / B operand.  Printed "0 mismatches" on MI355X (round 4).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef short s4 __attribute__((ext_vector_type(4)));
