@@ -52,8 +52,7 @@ int mmseg_conv2d_fwd(const float* x1, const float* x2, const float* w, const flo
 int mmseg_set_conv_precision(int mode);
 /* Which kernel multiplies 16-bit tensors with channel counts that are multiples of 64 (the UNet / SPADE 3x3 layers of
  * models/unet.py:94-101, layers/spade.py:26-33 in the reduced-precision configurations): 0 = always the 128-wide register-staged
- * kernel, 1 (default) = the 256-pixel direct-to-LDS kernel where the launch has enough tiles, 2 = wherever it applies (3 = as 2 with the
- * persistent grid cut to two blocks, so that tests make every block walk several output tiles).  Also gates the patch-resident fp32 kernels.  Same
+ * kernel, 1 (default) = the 256-pixel direct-to-LDS kernel where the launch has enough tiles, 2 = wherever it applies.  Same
  * 16-bit products and fp32 accumulation, K tiles of another depth: results agree to fp32 rounding.  Returns the previous mode; other
  * values only query. */
 int mmseg_conv16_mode(int mode);

@@ -2194,7 +2194,7 @@ extern "C" {
 // large-tile 16-bit kernel (conv16.hpp): 0 off, 1 where it pays (default), 2 wherever it applies; returns the previous mode
 int mmseg_conv16_mode(int mode) {
     const int old = g_conv16_mode;
-    if (mode >= 0 && mode <= 3) g_conv16_mode = mode;
+    if (mode >= 0 && mode <= 2) g_conv16_mode = mode;
     return old;
 }
 

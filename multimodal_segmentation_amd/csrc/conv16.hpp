@@ -269,8 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void conv16_kernel(ConvP
     conv16_body<BM, BN, WM, WN, NS, PREC>(p);
 }
 
-// 0: never use this kernel; 1 (default): where it pays; 2: wherever it applies (tests put small problems on it); 3: as 2 with the persistent
-// grid of the patch-resident kernel cut to two blocks (tests: every block walks several tiles) -- mmseg_conv16_mode
+// 0: never use this kernel; 1 (default): where it pays; 2: wherever it applies (tests put small problems on it) -- mmseg_conv16_mode
 static int g_conv16_mode = 1;
 // tile choice.  0 = leave the layer to conv_fast_kernel (too few 256-pixel tiles to fill the chip, or K tiles that straddle tensors)
 // what both kernels need: 16-bit inputs, channel counts multiples of 64 (a K tile inside one tap of one tensor), no output mapping,
@@ -291,7 +290,7 @@ static int conv16_tile(const ConvParams& p) {
     // mode 1: only where it measured faster than conv_fast_kernel (tools/conv16_bench.py, profiles/r04_conv16_ab.txt): at least 3/4 of a
     // wave of 256-pixel blocks on the 256 CUs, and more than 64 output channels (with a 64-wide tile every wave re-reads the whole weight
     // tile: LDS-read bound, 0.6 - 0.9 x the 128 x 64 tile of the register-staged kernel, which runs 3 blocks per CU)
-    if (force < 0 && g_conv16_mode < 2 && (mt * ((p.Cout + bn - 1) / bn) < 192 || bn == 64)) return 0;
+    if (force < 0 && g_conv16_mode != 2 && (mt * ((p.Cout + bn - 1) / bn) < 192 || bn == 64)) return 0;
     return bn;
 }
 template <int PREC>
@@ -349,13 +348,15 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 31, lh = lane >> 5;
-    // PERSISTENT blocks: the grid is one block per CU (or fewer); block b works on output tiles b, b + G, b + 2 G, ... and queues the next tile's
-    // patch and first weight tiles BEFORE it runs the epilogue of the current one, so the latency to the first landed tile (2 - 3 us, a fifth of a
-    // 16-bit tile's life) sits under the epilogue's arithmetic and stores instead of in front of an idle matrix pipe.
-    const int ntn = (p.Cout + BN - 1) / BN, ntm = p.M / (TH * TW), ntot = ntm * ntn;
+    const int nblk = gridDim.x;
+    const int ntn = (p.Cout + BN - 1) / BN, ntm = nblk / ntn;
+    const int lb = xcd_remap(blockIdx.x, nblk);
     const bool w_major = (long)p.K * p.Cout > (long)p.M * (p.C1 + p.C2);
+    const int mt = w_major ? lb % ntm : lb / ntn;
+    const int n0 = (w_major ? lb / ntm : lb % ntn) * BN;
     const int tpr = p.W / TW, tpi = (p.H / TH) * tpr;
-    int n0 = 0, t_b = 0, y0 = 0, x0 = 0;
+    const int t_b = mt / tpi, t_r = mt - t_b * tpi;
+    const int y0 = (t_r / tpr) * TH, x0 = (t_r % tpr) * TW;
 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * ES, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
@@ -365,39 +366,25 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
 
     // ---- patch pieces of this lane: piece pc = jj * NW + wid (jj = the tap during which it is loaded), pixel hp = 8 pc + (lane >> 3),
     // LDS chunk (lane & 7) <- source chunk (lane & 7) ^ ((hp >> 1) & 7); byte offsets in x1 / x2, FAR for pixels outside the image
-    int h_o1[PB == 2 ? PPW : 1], h_o2[PB == 2 ? PPW : 1];
-    int b_o[BG];
-    // byte offset of patch piece jj of this lane in x1 (first) / x2, FAR outside the image.  The two-buffer forms keep them in registers (one
-    // piece per tap is queued); the single-buffer forms (16 rows: 10 pieces per wave) recompute them in the reload burst -- 20 VGPRs that the
-    // 128 x 64 wave tile needs
-    auto patch_off = [&](const int jj, const bool first) -> int {
+    int h_o1[PPW], h_o2[PPW];
+#pragma unroll
+    for (int jj = 0; jj < PPW; ++jj) {
         const int pc = jj * NW + wid;
         const int hp = 8 * pc + (lane >> 3);
         const int hy = hp / HWD, hx = hp - hy * HWD;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         const int sc16 = 16 * ((lane & 7) ^ ((hp >> 1) & 7));
         const bool ok = hp < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        if (first) return ok ? (p.ups ? ((t_b * p.H1 + (y >> 1)) * p.W1 + (x >> 1)) : ((t_b * p.H + y) * p.W + x)) * p.C1 * ES + sc16 : FAR;
-        return (ok && p.C2) ? ((t_b * p.H + y) * p.W + x) * p.C2 * ES + sc16 : FAR;
-    };
-    auto setup_tile = [&](const int lt) {
-        const int lb = xcd_remap(lt, ntot);           // (lt & 7 = blockIdx.x & 7 when the grid is a multiple of 8: consecutive logical tiles share an XCD)
-        const int mt = w_major ? lb % ntm : lb / ntn;
-        n0 = (w_major ? lb / ntm : lb % ntn) * BN;
-        t_b = mt / tpi;
-        const int t_r = mt - t_b * tpi;
-        y0 = (t_r / tpr) * TH; x0 = (t_r % tpr) * TW;
-        if constexpr (PB == 2) {
+        h_o1[jj] = ok ? (p.ups ? ((t_b * p.H1 + (y >> 1)) * p.W1 + (x >> 1)) : ((t_b * p.H + y) * p.W + x)) * p.C1 * ES + sc16 : FAR;
+        h_o2[jj] = (ok && p.C2) ? ((t_b * p.H + y) * p.W + x) * p.C2 * ES + sc16 : FAR;
+    }
+    int b_o[BG];
 #pragma unroll
-            for (int jj = 0; jj < PPW; ++jj) { h_o1[jj] = patch_off(jj, true); h_o2[jj] = patch_off(jj, false); }
-        }
-#pragma unroll
-        for (int j = 0; j < BG; ++j) {
-            const int g = wid * BG + j;
-            const int n = n0 + 8 * g + (lane >> 3);
-            b_o[j] = n < p.Cout ? n * p.K * ES + 16 * ((lane & 7) ^ ((4 * g + (lane >> 4)) & 7)) : FAR;
-        }
-    };
+    for (int j = 0; j < BG; ++j) {
+        const int g = wid * BG + j;
+        const int n = n0 + 8 * g + (lane >> 3);
+        b_o[j] = n < p.Cout ? n * p.K * ES + 16 * ((lane & 7) ^ ((4 * g + (lane >> 4)) & 7)) : FAR;
+    }
     const int Cin2 = (p.C1 + p.C2) * ES;
     const int nch = (p.C1 + p.C2) / KT, nkt = nch * 9;
 
@@ -408,12 +395,8 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
         char* dst = smem + (PB == 2 ? (c & 1) * HALO : 0) + (jj * NW + wid) * 1024;
         const int c0 = c * KT;
         int off = 0;
-        if constexpr (PB == 2) {
 #pragma unroll
-            for (int q = 0; q < PPW; ++q) if (q == jj) off = c0 < p.C1 ? h_o1[q] : h_o2[q];      // (static register names)
-        } else {
-            off = patch_off(jj, c0 < p.C1);
-        }
+        for (int q = 0; q < PPW; ++q) if (q == jj) off = c0 < p.C1 ? h_o1[q] : h_o2[q];      // (static register names)
         if (c0 < p.C1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, (lds_ptr)dst, 16, off + c0 * ES, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, (lds_ptr)dst, 16, off + (c0 - p.C1) * ES, 0, 0, 0);
         return 1;
@@ -484,18 +467,13 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
         }
     };
 
-    // ---- queue a tile's first loads: the whole patch of chunk 0, the first (NS - 1) SUP weight tiles
-    auto queue_first = [&]() {
+    // ---- prologue: the whole patch of chunk 0, the first (NS - 1) SUP weight tiles
 #pragma unroll
-        for (int jj = 0; jj < PPW; ++jj) issue_patch(0, jj);
+    for (int jj = 0; jj < PPW; ++jj) issue_patch(0, jj);
 #pragma unroll
-        for (int u = 0; u < (NS - 1) * SUP; ++u) issue_b(u, u / 9, u % 9, u < nkt);
-    };
-    int lt = blockIdx.x;
-    if (lt < ntot) { setup_tile(lt); queue_first(); }
-    for (; lt < ntot; lt += gridDim.x) {
-    // (everything queued so far has landed -- incl. the previous tile's output stores, which share the counter)
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int u = 0; u < (NS - 1) * SUP; ++u) issue_b(u, u / 9, u % 9, u < nkt);
+    if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BG) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     // position of K tile t: chunk c, tap (kh, kw); of the first weight tile queued in this interval (tile t + (NS - 1) SUP): (ci, ti)
     int c = 0, kh = 0, kw = 0, tap = 0;
     int ci = ((NS - 1) * SUP) / 9, ti = ((NS - 1) * SUP) % 9;
@@ -551,18 +529,15 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (zero-fill tiles queued past the end of K)
-    // every wave has passed the last K tile's barrier: LDS is free.  Remember where this tile's outputs go, then queue the NEXT tile's
-    // first loads and only then run the epilogue.
-    const int e_n0 = n0, e_tb = t_b, e_y0 = y0, e_x0 = x0;
-    if (lt + (int)gridDim.x < ntot) { setup_tile(lt + gridDim.x); queue_first(); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
     // ---- epilogue: accumulator tile (i, j) = 32 pixels of image row y0 + wm TM + i x 32 channels; quad-transposed 4-channel stores
     {
         const int tq = lane & 3;
         const int c1 = p.y2 == nullptr ? p.Cout : p.nsplit1, c2 = p.Cout - c1;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = e_n0 + wn * (BN / WN) + j * 32 + li;
+            const int n = n0 + wn * (BN / WN) + j * 32 + li;
             const bool nok = n < p.Cout;
             const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
             const float sv = (nok && p.oscale) ? p.oscale[n] : 1.f;
@@ -572,7 +547,7 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
             const int ocol = first ? nq : nq - c1, ocn = first ? c1 : c2;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int mrow = (e_tb * p.H + e_y0 + wm * TM + i) * p.W + e_x0 + 4 * lh + tq;
+                const int mrow = (t_b * p.H + y0 + wm * TM + i) * p.W + x0 + 4 * lh + tq;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float a[4];
@@ -585,13 +560,6 @@ __device__ __forceinline__ void conv16h_body(const ConvParams& p) {
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }      // tiles of this block
 }
 template <int BN, int WM, int WN, int NS, int PREC, int SUP = 1, int TH = 8, int PB = 2>
 __global__ __launch_bounds__(512, 2) void conv16h_kernel(ConvParams p) {
@@ -611,7 +579,7 @@ static double conv16h_tail(long blocks) {
     const long rounds = (blocks + 255) / 256;
     return (double)blocks / (double)(rounds * 256);
 }
-static bool conv16h_grid_ok(long blocks) { return g_conv16_mode >= 2 || (blocks >= 192 && conv16h_tail(blocks) >= 0.8); }
+static bool conv16h_grid_ok(long blocks) { return g_conv16_mode == 2 || (blocks >= 192 && conv16h_tail(blocks) >= 0.8); }
 static int conv16h_tile(const ConvParams& p, bool fp32 = false) {
     if (!(fp32 ? conv32h_applicable(p) : conv16_applicable(p))) return 0;
     static const int hmode = ab_int("MMSEG_CONV16H", 1);     // measurement builds: 0 = never
@@ -623,7 +591,7 @@ static int conv16h_tile(const ConvParams& p, bool fp32 = false) {
     // mode 1: where it measured faster than conv_fast_kernel (tools/conv16_bench.py, DTYPE=f32 for the fp32 instances): grids that fill
     // their last round of blocks; in fp32 more than 32 output channels (a 64-wide tile on 32 channels multiplies half of it by zero:
     // 0.63 x in fp32, still 1.16 x in bf16 where the alternative is further from its roofline)
-    if (g_conv16_mode < 2 && fp32 && p.Cout <= 32) return 0;
+    if (g_conv16_mode != 2 && fp32 && p.Cout <= 32) return 0;
     if (bn == 64) {                                          // 16 image rows per block (the 64-channel form)
         static const int h64 = ab_int("MMSEG_CONV16H_N64", 1);
         if (!h64 || p.H % 16) return 0;
@@ -642,21 +610,21 @@ static int conv16h_rows(const ConvParams& p, int bn) {
 }
 template <int PREC>
 static int launch_conv16h_prec(const ConvParams& p, int bn, hipStream_t st) {
-    const int rows = conv16h_rows(p, bn);
-    const long ntot = (long)(p.M / (rows * 32)) * ((p.Cout + bn - 1) / bn);
-    // persistent blocks: one per CU; each walks tiles b, b + G, ... (measurement builds: MMSEG_CONV16H_PERSIST=0 -> one block per tile)
-    static const int persist = ab_int("MMSEG_CONV16H_PERSIST", 1);
-    unsigned grid = (unsigned)((persist && ntot > 256) ? 256 : ntot);
-    if (g_conv16_mode == 3 && grid > 2) grid = 2;          // tests: every block walks several tiles
-    if (bn == 256) hipLaunchKernelGGL((conv16h_kernel<256, 2, 4, 2, PREC>), dim3(grid), dim3(512), 0, st, p);
+    const int ntm = p.M / 256;
+    if (bn == 256) hipLaunchKernelGGL((conv16h_kernel<256, 2, 4, 2, PREC>), dim3(ntm * ((p.Cout + 255) / 256)), dim3(512), 0, st, p);
     // (two K tiles per barrier, SUP = 2, measured within +-2 % of one per barrier on every shape -- tools/ab_sup.sh, profiles/r04_conv16_notes.txt
-    // -- so the product keeps the smaller-LDS three-stage form; the SUP = 2 instance exists in measurement builds only)
+    // -- so the product keeps the smaller-LDS three-stage form; the SUP = 2 instances exist in measurement builds only)
 #ifdef MMSEG_AB
-    else if (ab_int("MMSEG_CONV16H_SUP", 1) == 2 && bn == 128 && rows == 8)
-        hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 2, PREC, 2>), dim3(grid), dim3(512), 0, st, p);
+    else if (ab_int("MMSEG_CONV16H_SUP", 1) == 2 && bn == 128)
+        hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 2, PREC, 2>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
 #endif
-    else if (bn == 128 && rows == 16) hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC, 1, 16, 1>), dim3(grid), dim3(512), 0, st, p);
-    else if (bn == 128) hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC>), dim3(grid), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv16h_kernel<64, 8, 1, 3, PREC, 1, 16, 1>), dim3(grid), dim3(512), 0, st, p);
+    else if (bn == 128 && conv16h_rows(p, bn) == 16)
+        hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC, 1, 16, 1>), dim3((p.M / 512) * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
+    else if (bn == 128) hipLaunchKernelGGL((conv16h_kernel<128, 4, 2, 3, PREC>), dim3(ntm * ((p.Cout + 127) / 128)), dim3(512), 0, st, p);
+#ifdef MMSEG_AB
+    else if (ab_int("MMSEG_CONV16H_N64_TH8", 0))        // measurement builds: 8 rows, two patch buffers, wave tile 64 x 32
+        hipLaunchKernelGGL((conv16h_kernel<64, 4, 2, 3, PREC>), dim3(ntm), dim3(512), 0, st, p);
+#endif
+    else hipLaunchKernelGGL((conv16h_kernel<64, 8, 1, 3, PREC, 1, 16, 1>), dim3(p.M / 512), dim3(512), 0, st, p);
     return MMSEG_CHECK_LAUNCH();
 }

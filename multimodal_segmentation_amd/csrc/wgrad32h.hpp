@@ -197,7 +197,7 @@ static int wgrad32h_plan(const ConvParams& p, int* S_out, int* tpb_out) {
     long S = (target + nbk - 1) / nbk;
     if (S > ntiles / 8) S = ntiles / 8;
     if (S < 1) S = 1;
-    if (g_conv16_mode < 2 && nbk * S < 192) return 0;
+    if (g_conv16_mode != 2 && nbk * S < 192) return 0;
     long tpb = (ntiles + S - 1) / S;
     S = (ntiles + tpb - 1) / tpb;
     *S_out = (int)S; *tpb_out = (int)tpb;
@@ -365,7 +365,7 @@ static int wgrad16h_plan(const ConvParams& p, int* S_out, int* tpb_out) {
     long S = (target + nbk - 1) / nbk;
     if (S > ntiles / 2) S = ntiles / 2;
     if (S < 1) S = 1;
-    if (g_conv16_mode < 2 && nbk * S < 192) return 0;
+    if (g_conv16_mode != 2 && nbk * S < 192) return 0;
     long tpb = (ntiles + S - 1) / S;
     S = (ntiles + tpb - 1) / tpb;
     *S_out = (int)S; *tpb_out = (int)tpb;

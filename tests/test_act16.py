@@ -575,36 +575,3 @@ def test_16bit_patch_resident_weight_gradient(B, H, W, C1, C2, Cout, ups, acc, m
         assert torch.equal(dw2, outs[2])
     finally:
         N.call('mmseg_conv16_mode', prev)
-
-
-@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
-def test_persistent_blocks_walk_several_tiles(prec):
-    """the patch-resident convolution kernel runs one PERSISTENT block per CU: block b computes output tiles b, b + G, ... and queues the next
-    tile's first loads before the epilogue of the current one.  The forced small problems of the other tests give every block one tile; here the
-    grid is cut to two blocks (mmseg_conv16_mode 3), so each walks 12 tiles -- same per-tile arithmetic, bit-identical results"""
-    prevp = P.set_conv_precision(prec)
-    prev = N.call('mmseg_conv16_mode', 2)
-    try:
-        dt = torch.float32 if prec == 'fp32' else torch.bfloat16
-        B, H, W, C1, C2, Cout = 3, 32, 64, 64, 64, 128           # 3 x (32 / 16) x (64 / 32) pixel tiles x 1 N tile = 12 tiles... x 2 for 8-row forms
-        x1 = rnd(B, H, W, C1, seed=1).to(dt).to(DEV)
-        x2 = rnd(B, H, W, C2, seed=2).to(dt).to(DEV)
-        w = (rnd(3, 3, C1 + C2, Cout, seed=3) * 0.05).to(DEV)
-        b = rnd(Cout, seed=4).to(DEV)
-        wp = torch.empty(w.numel(), device=DEV)
-        N.call('mmseg_conv2d_wprep', w, wp, 3, 3, C1 + C2, Cout, 0)
-        outs = {}
-        for m16 in (2, 3):
-            N.call('mmseg_conv16_mode', m16)
-            y = torch.full((B, H, W, Cout), float('nan'), device=DEV, dtype=dt)
-            if prec == 'fp32':
-                N.call('mmseg_conv2d_fwd', x1, x2, w, wp, b, y, None, B, H, W, C1, C2, H, W, Cout, 3, 3, 1, 1, 1, 0, 0, 1, 0.0, 0)
-            else:
-                N.call('mmseg_conv2d_fwd_t', x1, x2, w, wp, b, y, None, B, H, W, C1, C2, H, W, Cout, 3, 3, 1, 1, 1, 0, 0, 1, 0.0, 0, 1 | 2 | 4)
-            assert N.call('mmseg_conv2d_last_kernel') // 1000000 == 17
-            outs[m16] = y
-        assert not torch.isnan(outs[3].float()).any()
-        assert torch.equal(outs[2], outs[3])
-    finally:
-        N.call('mmseg_conv16_mode', prev)
-        P.set_conv_precision(prevp)
