@@ -2191,6 +2191,34 @@ __global__ void wprep_parity_all_kernel(const float* __restrict__ w, float* __re
 #include "wgrad32h.hpp"
 
 extern "C" {
+// Conv2D(Cout, 3, 'same') of an 8-channel tensor in the 16-bit modes (conv8h_kernel, conv16.hpp): x [B,H,W,8] fp32 (hx 0) or the 16-bit type of
+// the active mode (hx = mode), w the Keras kernel [3,3,8,Cout] fp32, y [B,H,W,Cout] fp32 (hy 0) or 16-bit.  W % 32 == 0, Cout % 4 == 0.
+int mmseg_conv8h_fwd_t(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, int act, float alpha,
+                       int hx, int hy, void* stream) {
+    const int prec = g_conv_bf16;
+    if (prec == 0 || B <= 0 || H <= 0 || W <= 0 || (W & 31) || (Cout & 3) || act < 0 || act > 2) return (int)hipErrorInvalidValue;
+    if ((hx != 0 && hx != prec) || (hy != 0 && hy != prec)) return (int)hipErrorInvalidValue;
+    if ((long)B * H * W * 8 * 4 >= (1L << 31) - 64) return (int)hipErrorInvalidValue;
+    const uintptr_t al = hy ? 7 : 15;
+    if ((reinterpret_cast<uintptr_t>(y) & al) || (reinterpret_cast<uintptr_t>(x) & 15)) return (int)hipErrorInvalidValue;
+    if (hy && (Cout & 7)) return (int)hipErrorInvalidValue;        // (16-byte stores of a 16-bit output)
+    const int ntn = (Cout + 127) / 128;
+    const long items = (long)B * H * (W / 32) * ntn;
+    long blocks = (items + 3) / 4;
+    if (blocks > 512) blocks = 512;                   // 2 blocks of 4 waves per CU; a wave walks its items with a stride
+    if (blocks * 4 < ntn) blocks = (ntn + 3) / 4;     // (every column group gets a wave)
+    hipStream_t st = (hipStream_t)stream;
+    const float slope = act == 2 ? alpha : 1.f;
+#define L8(P, X, Y, R) hipLaunchKernelGGL((conv8h_kernel<P, 4, X, Y, R>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, bias, y, B, H, W, Cout, slope)
+#define L8R(P, X, Y) do { if (act == 1) L8(P, X, Y, true); else L8(P, X, Y, false); } while (0)
+#define L8P(P) do { if (hx) { if (hy) L8R(P, true, true); else L8R(P, true, false); } else { if (hy) L8R(P, false, true); else L8R(P, false, false); } } while (0)
+    if (prec == 1) L8P(1); else L8P(2);
+#undef L8R
+#undef L8P
+#undef L8
+    MMSEG_SET_LAST(20, 32, 128);
+    return MMSEG_CHECK_LAUNCH();
+}
 // large-tile 16-bit kernel (conv16.hpp): 0 off, 1 where it pays (default), 2 wherever it applies; returns the previous mode
 int mmseg_conv16_mode(int mode) {
     const int old = g_conv16_mode;

@@ -628,3 +628,157 @@ static int launch_conv16h_prec(const ConvParams& p, int bn, hipStream_t st) {
     else hipLaunchKernelGGL((conv16h_kernel<64, 8, 1, 3, PREC, 1, 16, 1>), dim3(p.M / 512), dim3(512), 0, st, p);
     return MMSEG_CHECK_LAUNCH();
 }
+
+// =====================================================================================================================================
+// conv8h: Conv2D(Cout, 3, padding='same') of an 8-CHANNEL tensor in the 16-bit modes -- the shared convolution of every SPADE unit
+// (layers/spade.py:28-29 of the reference: the 8-channel anatomy -> 128 hidden channels + ReLU) and the segmentor's first layer.
+// Round 2 / 3 ran it as im2col (72 + 24 zero columns per pixel written as 16-bit rows) + a 1x1 product on conv_fast_kernel with three
+// 32-deep K tiles: 0.06 of the MFMA peak, and bound by neither HBM nor the matrix pipe but by the per-block prologue / epilogue of a
+// K = 96 product.  The layer is OUTPUT-WRITE bound (16 - 32 bytes in, 256 bytes out per pixel: ~ 70 FLOP/byte), so:
+//   * no LDS, no barrier: on v_mfma_f32_32x32x16_* a lane's A operand is 8 consecutive k = the 8 channels of ONE tap of ONE pixel -- exactly
+//     one 16-byte (16-bit input) or 32-byte (fp32 input, converted on the fly) row of the NHWC tensor; lane half h takes tap 2 s + h of
+//     k-step s, so the nine taps are five k-steps (the tenth half-step multiplies zero weights).  Image borders = out-of-range buffer
+//     offsets = zeros;
+//   * the weights (9 x 8 x Cout, as 5 x TN fragments) live in REGISTERS for the whole launch; a wave computes 32 pixels x 32 TN output
+//     channels per work item (20 MFMAs at TN = 4) and walks items wave by wave (grid-stride): nothing is shared between waves;
+//   * epilogue: bias, activation; a 16-bit output tile (32 pixels x 128 channels = 8 KB, CONTIGUOUS in HBM when Cout = 128) goes through a
+//     per-wave LDS slab (rows padded to 272 bytes) and leaves as 16-byte stores, 1 KB contiguous per instruction -- measured: the 8-byte quad
+//     stores of the other kernels (64-byte runs) hold this store-bound layer at 1.05 TB/s.  The WEIGHTS are the MFMA's A operand (rows of
+//     the product = output channels, in an order that makes a lane's 16 accumulator registers 16 consecutive channels of one pixel): no
+//     lane transposition, two 16-byte LDS writes per 32 channels; fp32 output: 16-byte stores straight from the registers;
+//   * the next item's operand rows are requested before the epilogue of the current one.
+template <int PREC, bool X16>
+__device__ __forceinline__ void conv8h_load(typename LowPrec<PREC>::V8 (&af)[5], const __amdgpu_buffer_rsrc_t rx, int pix0, int yy, bool live, int H, int W,
+                                            int li, int lh) {
+    // pix0: index of the segment's first pixel in the [B*H*W] pixel list, yy its image row
+    typedef typename LowPrec<PREC>::V8 LV8;
+    typedef typename LowPrec<PREC>::T LT;
+    const int px = (pix0 % W) + li;                 // (W is a multiple of 32: cheap when a power of two, one 32-bit division otherwise)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int tap = 2 * s + lh;                 // lh = 0: taps 0 2 4 6 8; lh = 1: taps 1 3 5 7 (9: none)
+        const int kh = (s * 2) / 3 + (lh & ((s * 2) % 3 == 2)), kw = tap - kh * 3;
+        const int ys = yy + kh - 1, xs = px + kw - 1;
+        const bool ok = live && tap < 9 && (unsigned)ys < (unsigned)H && (unsigned)xs < (unsigned)W;
+        const int pix = pix0 + li + (kh - 1) * W + (kw - 1);
+        if constexpr (X16) {
+            af[s] = __builtin_bit_cast(LV8, buf_load4(rx, ok ? pix * 16 : BUF_OOB));
+        } else {
+            const f32x4 lo = buf_load4(rx, ok ? pix * 32 : BUF_OOB), hi = buf_load4(rx, ok ? pix * 32 + 16 : BUF_OOB);
+            af[s] = LV8{(LT)lo[0], (LT)lo[1], (LT)lo[2], (LT)lo[3], (LT)hi[0], (LT)hi[1], (LT)hi[2], (LT)hi[3]};
+        }
+    }
+}
+
+// ReLU, or the branch-free form of none (slope 1) / LeakyReLU (slope alpha)
+template <bool RELU>
+__device__ __forceinline__ float conv8h_act(float v, float slope) {
+    return RELU ? fmaxf(v, 0.f) : fmaxf(v, 0.f) + slope * fminf(v, 0.f);
+}
+
+constexpr int C8H_ROW = 272;                      // bytes per pixel row of the epilogue slab (256 + 16: see above)
+
+template <int PREC, int TN, bool X16, bool Y16, bool RELU>
+__global__ __launch_bounds__(256, 2) void conv8h_kernel(const void* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          void* __restrict__ y, int B, int H, int W, int Cout, float slope) {
+    typedef typename LowPrec<PREC>::V8 LV8;
+    typedef typename LowPrec<PREC>::T LT;
+    static_assert(TN == 4, "the epilogue slab holds 128 channels per pixel");
+    __shared__ __attribute__((aligned(16))) unsigned char slab_all[Y16 ? 4 * 32 * C8H_ROW : 16];
+    __shared__ __attribute__((aligned(16))) float bias_all[4][32 * TN];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ntn = (Cout + 32 * TN - 1) / (32 * TN);
+    const int segs = W / 32;
+    const int nt = (int)(((long)blockIdx.x * 4 + wid) % ntn);             // (a wave keeps ONE column group for the whole launch)
+    // ---- weight fragments of this lane (the MFMA's A operand: ROWS of the product = output channels): row i of column tile j is channel
+    //      16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3), so that the accumulator registers of a lane -- rows 8 g + 4 lh + e in register 4 g + e -- are
+    //      16 CONSECUTIVE channels of one pixel; k = 8 lh + c of k-step s = channel c of tap 2 s + lh
+    const int chan = 16 * ((li >> 2) & 1) + 4 * (li >> 3) + (li & 3);
+    LV8 bf[5][TN];
+    {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 72 * Cout * 4, 0x00020000);
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int tap = 2 * s + lh, n = (nt * TN + j) * 32 + chan;
+                const int o = (tap < 9 && n < Cout) ? (tap * 8 * Cout + n) * 4 : BUF_OOB;      // (out of range -> 0: no branch per element)
+                LV8 v;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = (LT)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, o, c * Cout * 4, 0));
+                bf[s][j] = v;
+            }
+    }
+    float* bias_s = bias_all[wid];
+    for (int c = lane; c < 32 * TN; c += 64) bias_s[c] = (bias && nt * 32 * TN + c < Cout) ? bias[nt * 32 * TN + c] : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, B * H * W * 8 * (X16 ? 2 : 4), 0x00020000);
+    // the (pixel row segment) items of this wave: its slot among the waves of the same column group, then a stride of their number
+    const int G = (int)gridDim.x * 4;
+    const int wslot = ((int)blockIdx.x * 4 + wid) / ntn, nslots = (G + ntn - 1 - nt) / ntn;
+    const int nseg = B * H * segs;
+    // image row of an item, advanced without a division per item: row index r = item / segs over all images, yy = r % H
+    const int dr = nslots / segs, ds = nslots - dr * segs, dyy = dr % H;
+    int seg = wslot % segs, yy = (wslot / segs) % H;
+    LV8 af[5];
+    conv8h_load<PREC, X16>(af, rx, wslot * 32, yy, wslot < nseg, H, W, li, lh);
+    for (int it = wslot; it < nseg; it += nslots) {
+        f32x16 acc[TN];                                                   // starts from the bias (the MFMA's C operand)
+        int boff = 16 * lh;
+        asm volatile("" : "+v"(boff));                                    // (re-read per item: hoisted out of the loop the table would occupy 64 registers)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + j * 32 + boff + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][4 * q + e] = b4[e];
+            }
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = LowPrec<PREC>::mfma(bf[s][j], af[s], acc[j]);
+        seg += ds; yy += dyy;
+        if (seg >= segs) { seg -= segs; ++yy; }
+        if (yy >= H) yy -= H;
+        conv8h_load<PREC, X16>(af, rx, (it + nslots) * 32, yy, it + nslots < nseg, H, W, li, lh);      // next item's rows: in flight during the epilogue
+        // accumulator: column = pixel li of the segment, registers = channels 32 j + 16 lh + 0..15 of the column group
+        const size_t mrow0 = (size_t)it * 32;                               // first pixel of the segment (items walk pixels in memory order)
+        if constexpr (Y16) {
+            unsigned char* slab = slab_all + wid * 32 * C8H_ROW;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                LV8 lo, hi;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { lo[r] = (LT)conv8h_act<RELU>(acc[j][r], slope); hi[r] = (LT)conv8h_act<RELU>(acc[j][8 + r], slope); }
+                if constexpr (!RELU) __builtin_amdgcn_sched_barrier(0);   // (one column tile at a time: 64 pending min / max results would spill)
+                *reinterpret_cast<LV8*>(slab + li * C8H_ROW + (j * 32 + 16 * lh) * 2) = lo;
+                *reinterpret_cast<LV8*>(slab + li * C8H_ROW + (j * 32 + 16 * lh) * 2 + 16) = hi;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int ch = (lane & 15) * 8 + nt * 128;                      // this lane's 8 channels (16 bytes) of pixel (lane >> 4) + 4 i
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pr = (lane >> 4) + 4 * i;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + pr * C8H_ROW + (lane & 15) * 16);
+                if (ch < Cout) *reinterpret_cast<f32x4*>(reinterpret_cast<LT*>(y) + (mrow0 + pr) * Cout + ch) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n0 = (nt * TN + j) * 32 + 16 * lh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n0 + 4 * q < Cout)
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + (mrow0 + li) * Cout + n0 + 4 * q) =
+                            f32x4{conv8h_act<RELU>(acc[j][4 * q], slope), conv8h_act<RELU>(acc[j][4 * q + 1], slope),
+                                  conv8h_act<RELU>(acc[j][4 * q + 2], slope), conv8h_act<RELU>(acc[j][4 * q + 3], slope)};
+            }
+        }
+    }
+}

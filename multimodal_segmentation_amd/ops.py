@@ -399,11 +399,17 @@ class _Conv2d(torch.autograd.Function):
             # reduced-precision modes, 8 input channels (the SPADE units' shared convolution, the segmentor's first): K = 72 is three
             # gathers of the generic kernel per output tile; instead the 72 (+24 zero) operand columns of every pixel are written
             # once as 16-bit rows and the product runs as a 1x1 convolution on the 16-bit MFMA fast path
-            half = torch.bfloat16 if prec == 1 else torch.float16
-            xcol = torch.empty((B, H, W, 96), dtype=half, device=x1.device)
-            N.call('mmseg_im2col8_t', x1, xcol, B, H, W, _h(x1), prec)
-            _conv_fwd_raw(xcol, None, None, _wprep_col8(w, Cout, wkey), bias, y, None, B, H, W, 96, 0, Ho, Wo, Cout, 1, 1, 1, 0, 0, 0, 0,
-                          ACT[act], alpha, 0)
+            if W % 32 == 0 and _h(y) in (0, prec) and ACT[act] <= 2 and N.call('mmseg_conv16_mode', -1) != 0:
+                # round 4: one launch, no im2col tensor -- a lane's MFMA operand is one pixel's 8 channels of one tap, read as it lies;
+                # the weights stay in registers (conv8h_kernel, csrc/conv16.hpp)
+                assert w.numel() == 72 * Cout and (bias is None or bias.numel() == Cout) and y.numel() == B * H * W * Cout
+                N.call('mmseg_conv8h_fwd_t', x1, w, bias, y, B, H, W, Cout, ACT[act], float(alpha), _h(x1), _h(y))
+            else:
+                half = torch.bfloat16 if prec == 1 else torch.float16
+                xcol = torch.empty((B, H, W, 96), dtype=half, device=x1.device)
+                N.call('mmseg_im2col8_t', x1, xcol, B, H, W, _h(x1), prec)
+                _conv_fwd_raw(xcol, None, None, _wprep_col8(w, Cout, wkey), bias, y, None, B, H, W, 96, 0, Ho, Wo, Cout, 1, 1, 1, 0, 0, 0, 0,
+                              ACT[act], alpha, 0)
         else:
             wt = _wprep(w, KH, KW, Cin, Cout, 0, wkey) if N.call('mmseg_conv2d_fast_path', C1, C2, Cout, 0) else None
             _conv_fwd_raw(x1, x2, w, wt, bias, y, None, B, H, W, C1, C2, Ho, Wo, Cout, KH, KW, stride, ph, pw, int(ups), 0,

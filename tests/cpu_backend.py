@@ -64,6 +64,13 @@ def conv16_mode(mode):
     return 1
 
 
+def conv8h_fwd_t(x, w, bias, y, B, H, W, Cout, act, alpha, hx, hy):
+    """Conv2D(Cout, 3, 'same') of an 8-channel tensor (16-bit modes of the HIP library; here plain fp32 arithmetic)"""
+    wk = w.reshape(3, 3, 8, Cout).permute(3, 2, 0, 1).float()
+    v = torch.nn.functional.conv2d(x.reshape(B, H, W, 8).float().permute(0, 3, 1, 2), wk, None if bias is None else bias.float(), padding=1)
+    y.copy_(_act(v, act, alpha).permute(0, 2, 3, 1).reshape(y.shape).to(y.dtype)); return 0
+
+
 def conv2d_parity_taps(K, stride, p):
     return (K - p + stride - 1) // stride if p < K else 0
 

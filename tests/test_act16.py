@@ -575,3 +575,73 @@ def test_16bit_patch_resident_weight_gradient(B, H, W, C1, C2, Cout, ups, acc, m
         assert torch.equal(dw2, outs[2])
     finally:
         N.call('mmseg_conv16_mode', prev)
+
+
+@pytest.mark.parametrize('B,H,W,Cout,act,x16', [
+    (2, 7, 32, 128, 1, False),       # the SPADE unit's shared convolution: fp32 anatomy, ReLU, one 128-wide column group
+    (1, 16, 64, 128, 1, True),       # 16-bit input rows (16 bytes per pixel), two segments per image row
+    (3, 5, 96, 64, 0, False),        # 64 output channels: half of the column group is masked
+    (1, 9, 32, 320, 2, True),        # three column groups, the last one partly filled (waves of different groups interleave)
+    (2, 3, 32, 40, 2, False),        # Cout % 8 == 0 only; LeakyReLU
+])
+def test_conv_of_8_channels_in_one_launch(B, H, W, Cout, act, x16, mode):
+    """conv8h_kernel (conv16.hpp): Conv2D(Cout, 3, 'same') of an 8-channel tensor -- a lane's MFMA operand is one tap of one pixel read as it
+    lies, the weights stay in registers -- against the fp64 oracle on the operands as the MFMA sees them (inputs and weights rounded to
+    the 16-bit type: exact products, fp32 sums), with fp32 and 16-bit output; every image border is an out-of-range buffer offset."""
+    from oracle import ops as O
+    x = rnd(B, H, W, 8, seed=1).to(mode)
+    xd = (x if x16 else x.float()).to(DEV)
+    w = (rnd(3, 3, 8, Cout, seed=2) * (2.0 / 72) ** 0.5).to(DEV)
+    b = rnd(Cout, seed=3).to(DEV)
+    hm = 1 if mode == torch.bfloat16 else 2
+    ys = {}
+    for out16 in (False, True):
+        y = torch.full((B, H, W, Cout), float('nan'), device=DEV, dtype=mode if out16 else torch.float32)
+        N.call('mmseg_conv8h_fwd_t', xd, w, b, y, B, H, W, Cout, act, 0.2, hm if x16 else 0, hm if out16 else 0)
+        assert N.call('mmseg_conv2d_last_kernel') // 1000000 == 20
+        ys[out16] = y
+    assert not torch.isnan(ys[False]).any()
+    assert torch.equal(ys[True], ys[False].to(mode)), 'a 16-bit output is the rounding of the fp32 output'
+    ref = O.conv2d(x.float().double(), w.to(mode).float().cpu().double(), b.cpu().double())
+    ref = torch.relu(ref) if act == 1 else (O.leaky_relu(ref, 0.2) if act == 2 else (torch.tanh(ref) if act == 3 else ref))
+    err = float((ys[False].cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, err
+    # without a bias
+    y = torch.empty((B, H, W, Cout), device=DEV)
+    N.call('mmseg_conv8h_fwd_t', xd, w, None, y, B, H, W, Cout, 0, 0.0, hm if x16 else 0, 0)
+    ref0 = O.conv2d(x.float().double(), w.to(mode).float().cpu().double(), None)
+    assert float((y.cpu().double() - ref0).abs().max()) <= 2e-5 * float(ref0.abs().max())
+
+
+def test_conv_of_8_channels_rejects_what_it_does_not_take(mode):
+    x = torch.zeros(1, 4, 48, 8, device=DEV); w = torch.zeros(3, 3, 8, 128, device=DEV); y = torch.zeros(1, 4, 48, 128, device=DEV)
+    with pytest.raises(N.NativeLibraryError):
+        N.call('mmseg_conv8h_fwd_t', x, w, None, y, 1, 4, 48, 128, 0, 0.0, 0, 0)           # W % 32 != 0
+    other = 2 if mode == torch.bfloat16 else 1
+    with pytest.raises(N.NativeLibraryError):
+        N.call('mmseg_conv8h_fwd_t', x, w, None, y, 1, 4, 32, 128, 0, 0.0, other, 0)       # 16-bit type of the other mode
+    with pytest.raises(N.NativeLibraryError):
+        N.call('mmseg_conv8h_fwd_t', x, w, None, y, 1, 4, 32, 128, 3, 0.0, 0, 0)           # tanh: the node keeps the im2col path for it
+
+
+def test_node_of_the_8_channel_conv_uses_the_one_launch_kernel_and_matches_the_im2col_path(mode):
+    """ops.conv2d on an 8-channel input in a 16-bit mode: conv8h_kernel when W % 32 == 0 (mmseg_conv16_mode != 0), else / before round 4
+    im2col rows + a 1x1 product; same operands, same MFMA, fp32 sums associated differently"""
+    B, H, W, Cout = 2, 16, 32, 128
+    x = rnd(B, H, W, 8, seed=5).to(DEV)
+    w = (rnd(3, 3, 8, Cout, seed=6) * 0.2).to(DEV)
+    b = rnd(Cout, seed=7).to(DEV)
+    prev = N.call('mmseg_conv16_mode', -1)
+    try:
+        outs = {}
+        for m16 in (0, 1):
+            N.call('mmseg_conv16_mode', m16)
+            with torch.no_grad():
+                outs[m16] = P.conv2d(x, w, b, 1, 'same', 'relu', 0.0, out_dtype=mode)
+            fam = N.call('mmseg_conv2d_last_kernel') // 1000000
+            assert (fam == 20) == (m16 == 1), fam
+        d = (outs[0].float() - outs[1].float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 * float(outs[0].float().abs().max())
+        assert float((d > 0).float().mean()) < 0.01       # (a 16-bit rounding flips only where the fp32 sums straddle a tie)
+    finally:
+        N.call('mmseg_conv16_mode', prev)
