@@ -42,9 +42,10 @@ TFLOP_PER_PAIR = {('film', 256): 1.630, ('spade', 256): 2.871, ('mmsdnet', 256):
 _FAMILY = {1: 'conv_fast_kernel', 2: 'conv_fwd_kernel', 3: 'conv_direct_kernel', 4: 'conv_fast_batched_kernel',
            5: 'conv_dgrad_s2k4_smallc_kernel', 6: 'conv_wgrad_tr_kernel', 7: 'conv_wgrad_fast_kernel', 8: 'conv_wgrad_kernel',
            9: 'conv_wgrad_c8_kernel', 10: 'pw_reduce_kernel', 11: 'smallk_conv_kernel', 12: 'pw_reduce_wgrad_kernel',
-           13: 'smallk_wgrad_kernel'}
+           13: 'smallk_wgrad_kernel', 22: 's2k3c9_wgrad_kernel'}
 HBM_BOUND_FAMILIES = ('pw_reduce_kernel', 'smallk_conv_kernel', 'pw_reduce_wgrad_kernel', 'smallk_wgrad_kernel', 'conv_direct_kernel', 'conv_direct_mfma_kernel',
-                      'conv_wgrad_c8_kernel', 'conv_dgrad_s2k4_smallc_kernel')
+                      'conv_wgrad_c8_kernel', 'conv_dgrad_s2k4_smallc_kernel', 'conv8h_kernel', 's2k3c9_fwd_kernel', 's2k3c9_dgrad_kernel',
+                      's2k3c9_wgrad_kernel')
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
 
 
@@ -53,6 +54,13 @@ def kernel_name(kid, prec):
     fam, rest = kid // 1000000, kid % 1000000
     if fam == 18:              # <input-channel planes, output-channel planes> of the patch-resident fp32 weight gradient
         return 'wgrad32h_kernel<%d, %d>' % (rest // 1000, rest % 1000)
+    if fam == 19:
+        return 'wgrad16h_kernel<%d>' % prec
+    if fam == 21:              # the modality encoder's first layer (csrc/s2conv.hpp): N field 16 = forward, 9 = data gradient
+        return 's2k3c9_fwd_kernel' if rest % 1000 == 16 else 's2k3c9_dgrad_kernel'
+    if fam == 20:              # <precision, column tiles per wave, 16-bit input, 16-bit output, ReLU>: the M tile field carries the three flags
+        fl = rest // 1000
+        return 'conv8h_kernel<%d, 4, %s, %s, %s>' % (prec, 'true' if fl & 1 else 'false', 'true' if fl & 2 else 'false', 'true' if fl & 4 else 'false')
     if fam in (16, 17):        # the large-tile 16-bit kernels: plain <pixels per block> * 1000 + <N tile> (no flag fields)
         bm, bn = rest // 1000, rest % 1000
         if fam == 16:          # <M tile, N tile, waves M, waves N, ring stages, precision>
@@ -120,8 +128,15 @@ class ConvTimer(object):
                 name, io = name[:-2], args[-1]       # same leading arguments + the 16-bit storage bits (x1, x2, y / dy)
             e1, e2, e3 = (2.0 if io & 1 else 4.0), (2.0 if io & 2 else 4.0), (2.0 if io & 4 else 4.0)
             if timer.enabled and name in ('mmseg_conv2d_fwd', 'mmseg_conv2d_fwd_scaled', 'mmseg_conv2d_wgrad',
-                                          'mmseg_conv2d_dgrad_parity', 'mmseg_conv2d_dgrad_parity_all'):
-                if name == 'mmseg_conv2d_dgrad_parity_all':
+                                          'mmseg_conv2d_dgrad_parity', 'mmseg_conv2d_dgrad_parity_all', 'mmseg_conv8h_fwd_t'):
+                if name == 'mmseg_conv8h_fwd_t':        # 3x3 'same' convolution of an 8-channel tensor (16-bit modes): x, w, bias, y, B, H, W, Cout, ..., hx, hy
+                    (B, H, W, Cout) = args[4:8]
+                    hx, hy = args[10], args[11]
+                    flops = 2.0 * B * H * W * 72 * Cout
+                    nbytes = (2.0 if hx else 4.0) * B * H * W * 8 + 4.0 * 72 * Cout + (2.0 if hy else 4.0) * B * H * W * Cout
+                    kind = 'conv_fwd_kernel'
+                    shape = ('fwd', B, H, W, 8, 0, Cout, 3, 3, '8h')
+                elif name == 'mmseg_conv2d_dgrad_parity_all':
                     (B, Ho, Wo, Cout, H, W, Cin, KH, KW, stride) = args[3:13]
                     # the parity classes together touch every (output pixel, tap) pair of the strided convolution once
                     flops = 2.0 * B * Ho * Wo * KH * KW * Cin * Cout

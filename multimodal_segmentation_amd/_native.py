@@ -48,7 +48,7 @@ def parse_header(path=HEADER_PATH):
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into one in-tree shared library (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC_DIR, h) for h in ('common.hpp', 'smallconv.hpp', 'conv16.hpp', 'wgrad32h.hpp')]
+    deps = srcs + [os.path.join(CSRC_DIR, h) for h in ('common.hpp', 'smallconv.hpp', 'conv16.hpp', 'wgrad32h.hpp', 's2conv.hpp')]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

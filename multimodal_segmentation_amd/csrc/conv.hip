@@ -781,7 +781,7 @@ static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
 // M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / 16-bit input of the fast kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
 // 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel,
 // 10 pw_reduce_kernel<LANES, COUT, VPL>, 12 pw_reduce_wgrad_kernel<...> (M tile field = LANES, N tile field = COUT);
-// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv_wgrad_tr_anyw_kernel; 16 conv16_kernel, 17 conv16h_kernel (M tile field = pixels per block), 18 wgrad32h_kernel<NCI, NCO>, 19 wgrad16h_kernel
+// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv_wgrad_tr_anyw_kernel; 16 conv16_kernel, 17 conv16h_kernel (M tile field = pixels per block), 18 wgrad32h_kernel<NCI, NCO>, 19 wgrad16h_kernel, 20 conv8h_kernel (M tile field = 16-bit x | 2 * 16-bit y | 4 * ReLU); 21 s2k3c9_fwd_kernel (N field 16) / s2k3c9_dgrad_kernel (N field 9), 22 s2k3c9_wgrad_kernel
 static int g_last_kernel = 0;
 #define MMSEG_SET_LAST(fam, bm, bn) (g_last_kernel = (fam) * 1000000 + (bm) * 1000 + (bn))
 template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false>
@@ -1062,6 +1062,7 @@ static int smallconv_dispatch(const ConvParams& p, hipStream_t st) {
 }
 
 #include "conv16.hpp"
+#include "s2conv.hpp"
 
 // the quad-transposed epilogue stores 4 channels per lane: 16-byte (fp32) / 8-byte (16-bit) aligned output rows
 static int quad_epilogue_ok(const ConvParams& p) {
@@ -1088,6 +1089,10 @@ static int conv_dispatch(ConvParams& p, hipStream_t st) {
     }
     {
         const int rc = smallconv_dispatch(p, st);
+        if (rc >= 0) return rc;
+    }
+    {
+        const int rc = s2conv_dispatch(p, st);       // the modality encoder's first layer (9 -> 16, 3x3, stride 2) and its data gradient
         if (rc >= 0) return rc;
     }
     const bool vec = (p.C1 % 4 == 0) && (p.C2 % 4 == 0) && aligned16(p.x1) && (p.C2 == 0 || aligned16(p.x2));
@@ -2216,7 +2221,7 @@ int mmseg_conv8h_fwd_t(const void* x, const float* w, const float* bias, void* y
 #undef L8R
 #undef L8P
 #undef L8
-    MMSEG_SET_LAST(20, 32, 128);
+    MMSEG_SET_LAST(20, (hx ? 1 : 0) | (hy ? 2 : 0) | (act == 1 ? 4 : 0), 128);      // (the M-tile field carries the instance flags)
     return MMSEG_CHECK_LAUNCH();
 }
 // large-tile 16-bit kernel (conv16.hpp): 0 off, 1 where it pays (default), 2 wherever it applies; returns the previous mode
@@ -2538,7 +2543,7 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
         if (wgrad16h_plan(p, &Sh, &tpb) && wgrad_ws_floats(Sh, KN) <= ws_floats) {
             const bool directh = Sh == 1 && !accumulate;
             q.ws = directh ? dw : ws;
-            const unsigned grid = (unsigned)(((C1 + C2) / 64) * (Cout / 64) * Sh);
+            const unsigned grid = (unsigned)(((C1 + C2) / 64) * ((Cout + 63) / 64) * Sh);
             if (g_conv_bf16 == 1) hipLaunchKernelGGL((wgrad16h_kernel<1>), dim3(grid), dim3(768), 0, st, q, tpb);
             else hipLaunchKernelGGL((wgrad16h_kernel<2>), dim3(grid), dim3(768), 0, st, q, tpb);
             MMSEG_SET_LAST(19, 64, 64);
@@ -2597,6 +2602,19 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
             else { if (L == 16) SMW(4, 16); else if (L == 4) SMW(4, 4); else SMW(4, 2); }
 #undef SMW
             MMSEG_SET_LAST(13, KH * 20 + L, 1);
+            launched = 1;
+        }
+        static const int s2_on = ab_int("MMSEG_S2CONV", 1);
+        if (!launched && s2_on && s2k3c9_geometry(p) && aligned16(dy) && (reinterpret_cast<uintptr_t>(x1) & 3) == 0) {
+            // the modality encoder's first layer (s2conv.hpp): one slab per block of four waves, each walking `steps` groups of 4 pixels
+            const long nsteps = ((long)p.M + 3) / 4;
+            long nb = cap < 512 ? cap : 512;
+            if (nb * 4 > nsteps) nb = (nsteps + 3) / 4;
+            if (nb < 1) nb = 1;
+            const int steps = (int)((nsteps + nb * 4 - 1) / (nb * 4));
+            nblk = (int)((nsteps + (long)steps * 4 - 1) / ((long)steps * 4));
+            hipLaunchKernelGGL(s2k3c9_wgrad_kernel, dim3(nblk), dim3(256), 0, st, p, dy, ws, steps);
+            MMSEG_SET_LAST(22, 16, 16);
             launched = 1;
         }
         if (launched) {

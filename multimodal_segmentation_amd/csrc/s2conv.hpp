@@ -1,0 +1,221 @@
+// First layer of the modality encoder: Conv2D(16, 3, strides=2, padding='valid') over Concatenate([anatomy (8 channels), image (1 channel)])
+// (model_components/modality_encoder.py:34-38 of the reference: `build_simple_encoder`), its data gradient and its weight gradient.
+// Included by conv.hip; fp32 tensors, fp32 arithmetic in every precision mode (the generic kernels these replace never multiplied this
+// layer in 16 bits either: 9 input channels are not a multiple of 4).
+//
+// K = 81, N = 16 and 9 output channels of the data gradient: on the 128 x 32 implicit-GEMM tiles the layer ran at 3 - 9 TFLOP/s -- 110 us
+// forward, 130 us weight gradient and 315 us data gradient per launch at 16 x 320 x 320 (30 launches each per MMSDNet iteration: 6.5 % of
+// the step) for 85 MB of tensors.  It is a bandwidth layer; here it runs on v_mfma_f32_16x16x4_f32 with operands read as they lie:
+//   forward        rows = 16 output channels (A = the kernel, 21 k-steps in registers), columns = 16 output pixels, a lane's B operand is
+//                  2 channels of one tap of its pixel (8-byte load) or the image value of one tap; a lane ends with 4 consecutive
+//                  channels of one pixel: 16-byte stores, 1 KB contiguous per wave
+//   data gradient  one launch row (blockIdx.y) per parity class of the input pixels -- each an exact stride-1 convolution of dy with 1, 2, 2
+//                  or 4 of the nine taps; rows = 9 input channels (of 16), columns = 16 input pixels of the class, a lane's B operand is
+//                  4 channels of dy of one tap (16-byte load)
+//   weight gradient rows = the 81 (tap, channel) pairs in 6 tiles of 16, columns = 16 output channels, K = 4 pixels per MFMA; the four
+//                  waves of a block add their tiles in LDS in a fixed order, one slab per block, then the library's slab reduction.
+// Sums are fp32 in a fixed order: deterministic like the rest of the library.
+
+typedef float s2_f32x2 __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ f32x4 s2_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+static __device__ __forceinline__ float s2_load1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+static __device__ __forceinline__ s2_f32x2 s2_load2(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(s2_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+}
+
+// y[b, ho, wo, n] = act(bias[n] + sum_{kh, kw} ( sum_{c < 8} x1[b, 2 ho + kh, 2 wo + kw, c] w[kh, kw, c, n] + x2[b, 2 ho + kh, 2 wo + kw] w[kh, kw, 8, n] ))
+__global__ __launch_bounds__(256) void s2k3c9_fwd_kernel(ConvParams p) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int nw = (int)gridDim.x * 4, w0 = (int)blockIdx.x * 4 + wid;
+    const int ntiles = (p.M + 15) / 16;
+    // A fragments: row j = output channel; k-step 2 tap + e holds channel 2 kq + e of the tap, k-step 18 + t the image channel of tap 4 t + kq
+    float aw[21];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) aw[2 * tap + e] = p.w[(tap * 9 + 2 * kq + e) * 16 + j];
+    int off2[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int tap = 4 * t + kq;
+        aw[18 + t] = tap < 9 ? p.w[(tap * 9 + 8) * 16 + j] : 0.f;
+        off2[t] = tap < 9 ? (tap / 3) * p.W + (tap % 3) : -1;
+    }
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * kq);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H * p.W * 8 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x2, 0, p.B * p.H * p.W * 4, 0x00020000);
+    for (int tile = w0; tile < ntiles; tile += nw) {
+        const int m = tile * 16 + j;
+        const bool live = m < p.M;
+        const int wo = m % p.Wo, t_ = m / p.Wo, ho = t_ % p.Ho, b = t_ / p.Ho;
+        const int pix0 = (b * p.H + 2 * ho) * p.W + 2 * wo;
+        s2_f32x2 xv[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) xv[tap] = s2_load2(r1, live ? ((pix0 + (tap / 3) * p.W + (tap % 3)) * 8 + 2 * kq) * 4 : BUF_OOB);
+        float iv[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) iv[t] = s2_load1(r2, (live && off2[t] >= 0) ? (pix0 + off2[t]) * 4 : BUF_OOB);
+        f32x4 acc = b4;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            acc = s2_mfma(aw[2 * tap], xv[tap][0], acc);
+            acc = s2_mfma(aw[2 * tap + 1], xv[tap][1], acc);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc = s2_mfma(aw[18 + t], iv[t], acc);
+        // lane (pixel j, row group kq): output channels 4 kq .. 4 kq + 3
+        if (live) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[r], p.act, p.alpha);
+            *reinterpret_cast<f32x4*>(p.y + (size_t)m * 16 + 4 * kq) = v;
+        }
+    }
+}
+
+// The launch is the library's fractionally strided data-gradient launch: p.x1 = dy [B, p.H, p.W, 16] (the forward OUTPUT plane), p.w the
+// flipped kernel wf[2 - kh][2 - kw][n][c] (mmseg_conv2d_wflip), p.y = d(anatomy) [B, p.Ho, p.Wo, 8], p.y2 = d(image) [B, p.Ho, p.Wo, 1] or null.
+// Input pixel (h, w) = (2 i + ph, 2 jx + pw) of class (ph, pw) receives tap (kh, kw) = (ph + 2 a, pw + 2 b) from dy[i - a, jx - b].
+__global__ __launch_bounds__(256) void s2k3c9_dgrad_kernel(ConvParams p) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int ph = (int)blockIdx.y >> 1, pw = (int)blockIdx.y & 1;
+    const int Hi = p.Ho, Wi = p.Wo;
+    const int Hc = (Hi - ph + 1) / 2, Wc = (Wi - pw + 1) / 2;
+    const int Mc = p.B * Hc * Wc, ntiles = (Mc + 15) / 16;
+    const int nw = (int)gridDim.x * 4, w0 = (int)blockIdx.x * 4 + wid;
+    // A fragments: row j = input channel c (9 of 16), k-step (tap, e) holds output channel n = 4 kq + e
+    f32x4 aw[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int kh = ph + 2 * a, kw = pw + 2 * b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                aw[a][b][e] = (kh < 3 && kw < 3 && j < 9) ? p.w[(((2 - kh) * 3 + (2 - kw)) * 16 + 4 * kq + e) * 9 + j] : 0.f;
+        }
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H * p.W * 16 * 4, 0x00020000);
+    for (int tile = w0; tile < ntiles; tile += nw) {
+        const int mc = tile * 16 + j;
+        const bool live = mc < Mc;
+        const int jx = mc % Wc, t_ = mc / Wc, i = t_ % Hc, b = t_ / Hc;
+        f32x4 g[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int ho = i - a, wo = jx - bb;
+                const bool ok = live && ph + 2 * a < 3 && pw + 2 * bb < 3 && (unsigned)ho < (unsigned)p.H && (unsigned)wo < (unsigned)p.W;
+                g[a][bb] = buf_load4(rg, ok ? (((b * p.H + ho) * p.W + wo) * 16 + 4 * kq) * 4 : BUF_OOB);
+            }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = s2_mfma(aw[a][bb][e], g[a][bb][e], acc);
+        // lane (pixel j, row group kq): input channels 4 kq .. 4 kq + 3 (8 = the image)
+        if (live) {
+            const size_t pix = ((size_t)b * Hi + 2 * i + ph) * Wi + 2 * jx + pw;
+            if (kq < 2) *reinterpret_cast<f32x4*>(p.y + pix * 8 + 4 * kq) = acc;
+            else if (kq == 2 && p.y2) p.y2[pix] = acc[0];
+        }
+    }
+}
+
+// slab[blockIdx.x][(tap * 9 + c) * 16 + n] = sum over this block's output pixels of xcat[pixel, tap, c] * dy[pixel, n].
+// MFMA rows: k' = 0 .. 71 the anatomy (tap * 8 + c), 72 .. 80 the image (tap); a wave walks `steps` groups of 4 consecutive pixels.
+__global__ __launch_bounds__(256) void s2k3c9_wgrad_kernel(ConvParams p, const float* __restrict__ dy, float* __restrict__ ws, int steps) {
+    __shared__ float red[4][6 * 4 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    // per-lane element offsets (floats, relative to the pixel's first tap) of the six row tiles
+    int offa[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int k = 16 * t + i, tap = k >> 3, c = k & 7;             // (tile 4: only i < 8 is an anatomy row)
+        offa[t] = ((tap / 3) * p.W + (tap % 3)) * 8 + c;
+    }
+    const int tap4 = i - 8;                                            // tile 4, i >= 8: image taps 0 .. 7; tile 5, i = 0: tap 8
+    const int offi4 = (tap4 / 3) * p.W + (tap4 % 3), offi5 = 2 * p.W + 2;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H * p.W * 8 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x2, 0, p.B * p.H * p.W * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, p.M * 16 * 4, 0x00020000);
+    f32x4 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = (p.M + 3) / 4;
+    const int s0 = ((int)blockIdx.x * 4 + wid) * steps, s1 = min(nsteps, s0 + steps);
+    for (int s = s0; s < s1; ++s) {
+        const int m = 4 * s + kq;
+        const bool live = m < p.M;
+        const int wo = m % p.Wo, t_ = m / p.Wo, ho = t_ % p.Ho, b = t_ / p.Ho;
+        const int pix0 = (b * p.H + 2 * ho) * p.W + 2 * wo;
+        float a[6];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = s2_load1(r1, live ? (pix0 * 8 + offa[t]) * 4 : BUF_OOB);
+        a[4] = s2_load1(r1, (live && i < 8) ? (pix0 * 8 + offa[4]) * 4 : BUF_OOB) + s2_load1(r2, (live && i >= 8) ? (pix0 + offi4) * 4 : BUF_OOB);
+        a[5] = s2_load1(r2, (live && i == 0) ? (pix0 + offi5) * 4 : BUF_OOB);
+        const float d = s2_load1(rd, live ? (m * 16 + i) * 4 : BUF_OOB);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc[t] = s2_mfma(a[t], d, acc[t]);
+    }
+    // the block's four partial tiles meet in LDS and are added in wave order
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wid][(t * 4 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    float* slab = ws + (size_t)blockIdx.x * (81 * 16);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int idx = tid + 256 * q;
+        const int l = idx & 63, r = (idx >> 6) & 3, t = idx >> 8;
+        const float v = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+        const int kp = 16 * t + 4 * (l >> 4) + r, n = l & 15;
+        if (kp < 81) {
+            const int k = kp < 72 ? (kp >> 3) * 9 + (kp & 7) : (kp - 72) * 9 + 8;
+            slab[k * 16 + n] = v;
+        }
+    }
+}
+
+static bool s2k3c9_geometry(const ConvParams& p) {
+    return p.KH == 3 && p.KW == 3 && p.stride == 2 && p.pad_h == 0 && p.pad_w == 0 && !p.ups && p.io == 0 && p.C1 == 8 && p.C2 == 1 && p.Cout == 16 &&
+           p.Ho == (p.H - 3) / 2 + 1 && p.Wo == (p.W - 3) / 2 + 1 && p.H >= 3 && p.W >= 3 && (long)p.B * p.H * p.W * 8 * 4 < (1L << 31) - 64 &&
+           (long)p.M * 16 * 4 < (1L << 31) - 64;
+}
+// forward / data-gradient launches of conv_dispatch: >= 0 = launched (hipError_t), -1 = not this layer
+static int s2conv_dispatch(const ConvParams& p, hipStream_t st) {
+    static const int on = ab_int("MMSEG_S2CONV", 1);            // measurement builds: 0 = the generic kernels
+    if (!on) return -1;
+    const bool plain = p.oscale == nullptr && p.osh == 1 && p.osw == 1 && p.ooh == 0 && p.oow == 0 && p.oH == p.Ho && p.oW == p.Wo;
+    if (!p.transposed && plain && p.y2 == nullptr && p.w != nullptr && s2k3c9_geometry(p) && aligned16(p.y) && aligned16(p.w) &&
+        (reinterpret_cast<uintptr_t>(p.x1) & 7) == 0 && (p.bias == nullptr || aligned16(p.bias))) {
+        long blocks = ((p.M + 15) / 16 + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(s2k3c9_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        MMSEG_SET_LAST(21, 16, 16);
+        return MMSEG_CHECK_LAUNCH();
+    }
+    // the data gradient arrives as a fractionally strided launch over dy: 16 input channels, 9 outputs split 8 + 1, padding K - 1
+    if (p.transposed && plain && p.w != nullptr && p.KH == 3 && p.KW == 3 && p.stride == 2 && p.pad_h == 2 && p.pad_w == 2 && !p.ups && p.io == 0 &&
+        p.C1 == 16 && p.C2 == 0 && p.Cout == 9 && p.y2 != nullptr && p.nsplit1 == 8 && p.bias == nullptr && p.act == 0 &&
+        p.H == (p.Ho - 3) / 2 + 1 && p.W == (p.Wo - 3) / 2 + 1 && aligned16(p.x1) && aligned16(p.y) &&
+        (long)p.B * p.Ho * p.Wo * 8 * 4 < (1L << 31) - 64 && (long)p.B * p.H * p.W * 16 * 4 < (1L << 31) - 64) {
+        const long mc = (long)p.B * ((p.Ho + 1) / 2) * ((p.Wo + 1) / 2);          // the largest parity class
+        long blocks = ((mc + 15) / 16 + 3) / 4;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(s2k3c9_dgrad_kernel, dim3((unsigned)blocks, 4), dim3(256), 0, st, p);
+        MMSEG_SET_LAST(21, 16, 9);
+        return MMSEG_CHECK_LAUNCH();
+    }
+    return -1;
+}

@@ -237,11 +237,12 @@ __device__ __forceinline__ void wgrad16h_body(const WgradParams& q, const int tp
     const int kh = wid % 3, pl = wid / 3;
     const int ha = pl >> 1, hb = pl & 1;                                  // this wave's 32-channel half of the input / output plane
     const int Cin = p.C1 + p.C2;
-    const int ncb = Cin / 64, nnb = p.Cout / 64;
+    const int ncb = Cin / 64, nnb = (p.Cout + 63) / 64;                   // (Cout % 64 == 32: the last output plane is half filled)
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int cb = bid % ncb, nb = (bid / ncb) % nnb, s = bid / (ncb * nnb);
     const int tw = p.W / 32, th = p.H / TH, tpi = tw * th, ntiles = p.B * tpi;
     const int t0 = s * tpb, t1 = min(ntiles, t0 + tpb);
+    const bool idle = nb * 64 + hb * 32 >= p.Cout;                        // this wave's output half lies beyond Cout: it loads and meets the barriers only
 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H1 * p.W1 * p.C1 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C2 ? p.x2 : p.x1), 0,
@@ -275,9 +276,10 @@ __device__ __forceinline__ void wgrad16h_body(const WgradParams& q, const int tp
             } else {
                 const int pp = id - XPC;
                 const int pix = 8 * pp + (lane >> 3);                     // row pix >> 5, column pix & 31 of the tile
-                const int sc16 = 16 * ((lane & 7) ^ (4 * ((pix >> 1) & 1)));
+                const int sc = (lane & 7) ^ (4 * ((pix >> 1) & 1)), sc16 = 16 * sc;
                 const int m = (b * p.H + TH * ty + (pix >> 5)) * p.W + 32 * tx + (pix & 31);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr)(base + XP + pp * 1024), 16, (m * p.Cout + nb * 64) * 2 + sc16, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr)(base + XP + pp * 1024), 16,
+                                                         nb * 64 + 8 * sc < p.Cout ? (m * p.Cout + nb * 64) * 2 + sc16 : FAR, 0, 0, 0);
             }
         }
     };
@@ -334,11 +336,12 @@ __device__ __forceinline__ void wgrad16h_body(const WgradParams& q, const int tp
         for (int t = t0; t < t1; ++t) {
             const int stage = (t - t0) & 1;
             if (t + 1 < t1) issue_tile(t + 1, stage ^ 1);
-            mma_tile(stage);
+            if (!idle) mma_tile(stage);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
 
+    if (idle) return;
     float* slab = q.ws + (size_t)s * ((size_t)p.K * p.Cout);
     const int co = nb * 64 + hb * 32 + li;
 #pragma unroll
@@ -353,13 +356,13 @@ template <int PREC>
 __global__ __launch_bounds__(768, 3) void wgrad16h_kernel(WgradParams q, int tpb) {
     wgrad16h_body<PREC>(q, tpb);
 }
-// plan of the 16-bit form: 1 if applicable (64-channel planes, 8-row tiles)
+// plan of the 16-bit form: 1 if applicable (64-channel planes -- the last output plane may be half filled --, 8-row tiles)
 static int wgrad16h_plan(const ConvParams& p, int* S_out, int* tpb_out) {
     static const int on = ab_int("MMSEG_WGRAD16H", 1);
     if (!on || g_conv_bf16 == 0 || (p.io & 5) != 5 || g_conv16_mode == 0) return 0;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1 || p.Ho != p.H || p.Wo != p.W) return 0;
-    if (p.W % 32 || p.H % 8 || p.C1 % 64 || p.C2 % 64 || p.Cout % 64) return 0;
-    const long nbk = (long)((p.C1 + p.C2) / 64) * (p.Cout / 64);
+    if (p.W % 32 || p.H % 8 || p.C1 % 64 || p.C2 % 64 || p.Cout % 32) return 0;
+    const long nbk = (long)((p.C1 + p.C2) / 64) * ((p.Cout + 63) / 64);
     const long ntiles = (long)p.B * (p.H / 8) * (p.W / 32);
     static const int target = ab_int("MMSEG_WGRAD16H_BLOCKS", 256);
     long S = (target + nbk - 1) / nbk;

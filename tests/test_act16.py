@@ -535,6 +535,8 @@ def test_fp32_patch_resident_weight_gradient(B, H, W, C1, C2, Cout, ups, acc):
     (2, 8, 32, 128, 0, 64, 1, 0),           # up-sampled x1, two input planes
     (1, 24, 32, 64, 64, 64, 0, 0),          # concatenated inputs, three tiles down one column strip
     (3, 8, 64, 192, 0, 128, 0, 1),          # three input planes, batch 3
+    (2, 16, 32, 128, 0, 32, 0, 0),          # Cout = 32: one half-filled output plane (the fused gamma / beta convolution of a 16-channel SPADE unit)
+    (1, 8, 64, 64, 0, 96, 0, 1),            # Cout = 96: a full and a half-filled plane
 ])
 def test_16bit_patch_resident_weight_gradient(B, H, W, C1, C2, Cout, ups, acc, mode):
     """wgrad16h_kernel (round 4: operands through ds_read_b64_tr_b16 from the [pixel][channel] image in LDS) forced onto small problems

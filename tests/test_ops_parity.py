@@ -128,6 +128,11 @@ CONV_CASES = [
     # straddle row and sample boundaries, stride 2 and stride 1, a pixel count that is not a multiple of 4)
     (3, 64, 60, 64, 0, 128, 4, 2, 'valid', 'leaky', False),    # Ho x Wo = 31 x 29
     (3, 30, 30, 64, 0, 256, 4, 1, 'valid', 'leaky', False),    # 27 x 27: M = 2187
+    # round 4: the modality encoder's first layer on its own kernels (csrc/s2conv.hpp): parity classes of different sizes, pixel counts
+    # that fill neither the last 16-pixel tile nor the last group of 4, an even height whose last row no tap reaches
+    (3, 20, 37, 8, 1, 16, 3, 2, 'valid', 'leaky', False),
+    (1, 64, 64, 8, 1, 16, 3, 2, 'valid', None, False),
+    (5, 7, 9, 8, 1, 16, 3, 2, 'valid', 'leaky', False),
 ]
 
 
@@ -159,6 +164,28 @@ def test_conv2d(case, device):
         return y
 
     check(f_prod, f_ref, inputs, device, param_idx=(1, 2))
+
+
+@pytest.mark.gpu
+def test_modality_encoder_first_layer_runs_on_its_own_kernels():
+    """Conv2D(16, 3, strides=2, 'valid') over Concatenate([anatomy 8, image 1]) (modality_encoder.py:34-38 of the reference): forward, weight
+    gradient and data gradient leave the generic implicit-GEMM kernels (csrc/s2conv.hpp; values: the CONV_CASES above against the oracle)"""
+    from multimodal_segmentation_amd import _native as N
+    dev = 'cuda'
+    x1 = rnd(2, 33, 35, 8, seed=1).to(dev)
+    x2 = rnd(2, 33, 35, 1, seed=2).to(dev)
+    w = rnd(3, 3, 9, 16, seed=3, scale=0.2).to(dev)
+    b = rnd(16, seed=4, scale=0.1).to(dev)
+    for need_dx in (False, True):
+        xa = x1.clone().requires_grad_(need_dx)
+        wg, bg = torch.zeros_like(w), torch.zeros_like(b)
+        anchor = torch.zeros(1, device=dev, requires_grad=True)
+        y = P.conv2d(xa, w, b, stride=2, padding='valid', act='leaky', alpha=0.2, x2=x2, wgrad=wg, bgrad=bg, anchor=anchor)
+        assert N.call('mmseg_conv2d_last_kernel') == 21016016
+        y.backward(torch.ones_like(y))
+        # the backward node queues the weight gradient, then (if an input wants it) the data gradient
+        assert N.call('mmseg_conv2d_last_kernel') == (21016009 if need_dx else 22016016)
+        assert float(wg.abs().sum()) > 0
 
 
 @pytest.mark.parametrize('B,H,W,Cin,f,alpha', [(2, 12, 10, 128, 32, 0.2), (2, 9, 11, 128, 16, -1.0), (1, 16, 16, 128, 128, 0.2),
