@@ -1292,6 +1292,114 @@ __global__ __launch_bounds__(256) void conv_wgrad_c8_kernel(const float* __restr
         ws[(size_t)blockIdx.x * 576 + o] = red[o] + red[576 + o] + red[1152 + o] + red[1728 + o];
 }
 
+// The same weight gradient on v_mfma_f32_4x4x1_16B_f32 (round 4): the instruction's 16 blocks are 16 consecutive pixels, block rows = 4 input
+// channels, block columns = 4 output channels -- each block accumulates its own pixel stream; the 16 streams (and the waves) meet once per
+// launch in a fixed order.  Wave (h, q) owns input-channel half h and output-channel half q: 9 tap accumulators (36 registers), per 16 pixels
+// one ds_read_b32 of dy, nine of x and 9 MFMAs, no VALU arithmetic.  The tile (same 8 x 64 pixels + halo as above) is staged AS IT LIES, two
+// 16-byte writes per pixel; the two halves of a pixel swap places when bit 3 of its column is set, so that the 16 pixels of a read (32-byte
+// stride: p and p + 8 would meet in a bank) cover the 64 banks once; the tile loop is fully unrolled: an operand address is one of four per-lane
+// offsets plus an immediate (the first version computed the swizzle per read: 5 VALU per MFMA, slower than the VALU kernel).  The VALU kernel above spent 36 FMAs x 4 cycles per 4 pixels and a transposing LDS stage
+// (4 ds_write_b32 per loaded vector).
+__global__ __launch_bounds__(256) void conv_wgrad_c8m_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ ws, int B, int H, int W, int ntiles) {
+    constexpr int PW = 80;                                             // patch row pitch in pixels (66 used): a multiple of 16, so that bit 3 of a
+                                                                       // pixel's index -- the swizzle key -- is bit 3 of its COLUMN
+    __shared__ __attribute__((aligned(16))) float xs[(WG8_ROWS + 2) * PW * 8];
+    __shared__ __attribute__((aligned(16))) float dys[WG8_ROWS * WG8_COLS * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int blk = lane >> 2, i4 = lane & 3;
+    const int h = wid >> 1, q = wid & 1;
+    const int tpr = W / WG8_COLS, tpi = (H / WG8_ROWS) * tpr;
+    // per-lane operand offsets (floats): everything else of an address is a compile-time constant of the unrolled tile loop
+    int offx[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) offx[kw] = blk * 8 + 4 * (h ^ (((blk + kw) >> 3) & 1)) + i4;
+    const int offd = blk * 8 + 4 * (q ^ (blk >> 3)) + i4;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, B * H * W * 8 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, B * H * W * 8 * 4, 0x00020000);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tpi, tr = tile - b * tpi;
+        const int r0 = (tr / tpr) * WG8_ROWS, c0 = (tr % tpr) * WG8_COLS;
+        // all of the tile's loads are requested before the first LDS write (branch-free: halo pixels outside the image get an out-of-range
+        // offset and read as zeros) -- one exposed memory latency per tile, not one per staging iteration
+        constexpr int NXP = (WG8_ROWS + 2) * (WG8_COLS + 2), XIT = (NXP + 255) / 256, DIT = WG8_ROWS * WG8_COLS / 256;
+        f32x4 xv[XIT][2], dv[DIT][2];
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int i = tid + 256 * it;
+            const int pr = i / (WG8_COLS + 2), pc = i - pr * (WG8_COLS + 2);
+            const int hi = r0 + pr - 1, wi = c0 + pc - 1;
+            const bool ok = i < NXP && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+            const int off = (((b * H + hi) * W + wi) * 8) * 4;
+            xv[it][0] = buf_load4(rx, ok ? off : BUF_OOB);
+            xv[it][1] = buf_load4(rx, ok ? off + 16 : BUF_OOB);
+        }
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int i = tid + 256 * it;
+            const int pr = i / WG8_COLS, pc = i - pr * WG8_COLS;
+            const int off = (((b * H + r0 + pr) * W + c0 + pc) * 8) * 4;
+            dv[it][0] = buf_load4(rd, off);
+            dv[it][1] = buf_load4(rd, off + 16);
+        }
+        __syncthreads();                                   // previous tile fully consumed (its loads above were already in flight)
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int i = tid + 256 * it;
+            const int pr = i / (WG8_COLS + 2), pc = i - pr * (WG8_COLS + 2);
+            const int sw = (pc >> 3) & 1;
+            float* dst = xs + (pr * PW + pc) * 8;
+            if (i < NXP) {
+                *reinterpret_cast<f32x4*>(dst + 4 * sw) = xv[it][0];
+                *reinterpret_cast<f32x4*>(dst + 4 * (sw ^ 1)) = xv[it][1];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int i = tid + 256 * it;
+            const int sw = ((i % WG8_COLS) >> 3) & 1;
+            *reinterpret_cast<f32x4*>(dys + i * 8 + 4 * sw) = dv[it][0];
+            *reinterpret_cast<f32x4*>(dys + i * 8 + 4 * (sw ^ 1)) = dv[it][1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int row = 0; row < WG8_ROWS; ++row)
+#pragma unroll
+            for (int cg = 0; cg < WG8_COLS / 16; ++cg) {
+                const float g = dys[(row * WG8_COLS + 16 * cg) * 8 + offd];                   // dy[pixel][co = 4 q + i4]
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float a = xs[((row + kh) * PW + 16 * cg + kw) * 8 + offx[kw]];  // x[pixel + tap][ci = 4 h + i4]
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, g, acc[kh * 3 + kw], 0, 0, 0);
+                    }
+            }
+    }
+    // the 16 pixel streams of a wave: a fixed butterfly over the lane groups; register r of lane (block, j) = D[block][ci = 4 h + r][co = 4 q + j]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[t][r];
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            acc[t][r] = v;
+        }
+    if (lane < 4) {
+        float* slab = ws + (size_t)blockIdx.x * 576;        // [tap][ci][co]: every element has ONE owner (wave = channel halves, lane = column)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[t * 64 + (4 * h + r) * 8 + 4 * q + lane] = acc[t][r];
+    }
+}
+
 // =====================================================================================
 // wgrad: dW[k, n] = sum_m A[m, k] dy[m, n]
 // =====================================================================================
@@ -2558,7 +2666,9 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
         Wo == W && H % WG8_ROWS == 0 && W % WG8_COLS == 0 && S > 1 && aligned16(x1) && aligned16(dy)) {
         const int ntiles = B * (H / WG8_ROWS) * (W / WG8_COLS);
         const int nblk = ntiles < S ? ntiles : S;
-        hipLaunchKernelGGL(conv_wgrad_c8_kernel, dim3(nblk), dim3(256), 0, st, x1, dy, ws, B, H, W, ntiles);
+        static const int c8_mfma = ab_int("MMSEG_WGRAD_C8_MFMA", 1);       // 0 (measurement builds): the VALU kernel
+        if (c8_mfma && (long)B * H * W * 32 < (1L << 31) - 64) hipLaunchKernelGGL(conv_wgrad_c8m_kernel, dim3(nblk), dim3(256), 0, st, x1, dy, ws, B, H, W, ntiles);
+        else hipLaunchKernelGGL(conv_wgrad_c8_kernel, dim3(nblk), dim3(256), 0, st, x1, dy, ws, B, H, W, ntiles);
         MMSEG_SET_LAST(9, 8, 8);
         launch_slab_reduce(ws, tmp, dw, KN, nblk, accumulate, st);
         return MMSEG_CHECK_LAUNCH();

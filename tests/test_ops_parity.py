@@ -105,6 +105,7 @@ CONV_CASES = [
     (2, 8, 8, 256, 0, 512, 3, 1, 'same', None, False),
     (3, 128, 128, 64, 0, 128, 3, 1, 'same', 'relu', False),
     (2, 128, 128, 8, 0, 8, 3, 1, 'same', 'leaky', False),      # large M, tiny C: folded column-sum path
+    (3, 16, 192, 8, 0, 8, 3, 1, 'same', None, False),          # ... three tiles per row band, batch 3 (weight gradient on the 4x4x1 MFMA)
     (2, 96, 96, 64, 0, 5, 1, 1, 'same', None, False),          # large M, C not dividing 64: generic column sums
     (2, 33, 31, 1, 0, 64, 4, 2, 'valid', 'leaky', False),      # D_Image first layer, odd sizes: direct small-Cin data gradient
     (2, 33, 33, 16, 0, 32, 3, 2, 'valid', 'leaky', False),     # modality-encoder layer: batched parity classes with 2x1 / 1x1 taps
