@@ -187,6 +187,125 @@ __global__ __launch_bounds__(256) void s2k3c9_wgrad_kernel(ConvParams p, const f
     }
 }
 
+// =====================================================================================================================================
+// First layer of the localisation network of the anatomy fuser: Conv2D(20, 5, padding='valid') + LeakyReLU(0.3) over
+// Concatenate([anatomy 1 (8 channels), anatomy 2 (8 channels)]) (layers/stn_spline.py:98-103 of the reference: `build_locnet`), forward.
+// 16 input channels and 20 outputs fit no tile of the implicit-GEMM kernels (0.21 of the fp32 peak; 69 TFLOP/s with 16-bit operands); the
+// layer reads 16 x 25 values per output pixel that all sit in L1 / L2.  16-bit modes (this kernel; the operands are rounded exactly where
+// the generic kernel's 16-bit instance rounded them): v_mfma_f32_16x16x32_*, rows = output channels (2 tiles of 16: 20 used), columns = 16
+// output pixels, a k-step = 4 taps x the 8 channels of ONE tensor.  A block owns 8 x 64 output pixels: its 12 x 68-pixel input patch is
+// converted once into LDS (a pixel = 16 channels = 32 bytes), a lane's B operand -- 8 channels of one tensor of one tap of its pixel -- is
+// ONE ds_read_b128; the kernel (14 k-steps x 2 row tiles of 4 registers) stays in registers; a wave multiplies two pixel tiles per pass.
+// A lane ends with 4 consecutive channels of a pixel: 16-byte stores.  (First version: the operands straight from global memory, 28 KB of
+// 16-byte loads per 16 pixels -- as slow as the generic kernel: four waves' rows did not fit the 32 KB L1.)
+constexpr int LN5_TH = 8, LN5_TW = 64, LN5_PW = LN5_TW + 4, LN5_PH = LN5_TH + 4;
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void locnet5_fwd_kernel(ConvParams p) {
+    typedef typename LowPrec<PREC>::V8 LV8;
+    typedef typename LowPrec<PREC>::T LT;
+    constexpr int NG = 7;                           // tap groups of 4 (25 taps)
+    // the block's input patch, 16-bit, a pixel = [8 channels of x1 | 8 channels of x2] = 32 bytes: a lane's B operand is ONE ds_read_b128
+    __shared__ __attribute__((aligned(16))) LT patch[LN5_PH * LN5_PW * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 15, kg = lane >> 4;
+    const int tw = (p.Wo + LN5_TW - 1) / LN5_TW, th = (p.Ho + LN5_TH - 1) / LN5_TH;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H * p.W * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x2, 0, p.B * p.H * p.W * 32, 0x00020000);
+    constexpr int NPX = LN5_PH * LN5_PW, NIT = (NPX + 255) / 256;
+    // A fragments: row j (+ 16 rt) = output channel, k = 8 kg + c = channel c of tap 4 g + kg of tensor t; fetched ONCE per block (a block
+    // walks tiles bid, bid + gridDim.x, ...: 224 scalar loads per lane would otherwise cost more than a tile's arithmetic)
+    LV8 aw[NG][2][2];
+    int tapoff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int tap = 4 * g + kg;
+        tapoff[g] = tap < 25 ? ((tap / 5) * LN5_PW + (tap % 5)) * 16 : 0;         // (elements; taps 25 .. 27 multiply zero weights)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int n = 16 * rt + j;
+                LV8 v;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = (tap < 25 && n < 20) ? (LT)p.w[(tap * 16 + 8 * t + c) * 20 + n] : (LT)0.f;
+                aw[g][t][rt] = v;
+            }
+    }
+    f32x4 b4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (p.bias) {
+        b4[0] = *reinterpret_cast<const f32x4*>(p.bias + 4 * kg);
+        if (kg == 0) b4[1] = *reinterpret_cast<const f32x4*>(p.bias + 16);
+    }
+    for (int bid = (int)blockIdx.x; bid < p.B * tw * th; bid += (int)gridDim.x) {
+    const int b = bid / (tw * th), tr = bid - b * (tw * th), ty = tr / tw, tx = tr - ty * tw;
+    const int r0 = ty * LN5_TH, c0 = tx * LN5_TW;
+    // stage: all loads first (branch-free, out-of-image pixels read as zeros), then the converted rows
+    f32x4 xv[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        const int pr = i / LN5_PW, pc = i - pr * LN5_PW;
+        const int hi = r0 + pr, wi = c0 + pc;
+        const int off = (i < NPX && hi < p.H && wi < p.W) ? ((b * p.H + hi) * p.W + wi) * 32 : BUF_OOB;
+        xv[it][0] = buf_load4(r1, off); xv[it][1] = buf_load4(r1, off == BUF_OOB ? BUF_OOB : off + 16);
+        xv[it][2] = buf_load4(r2, off); xv[it][3] = buf_load4(r2, off == BUF_OOB ? BUF_OOB : off + 16);
+    }
+    __syncthreads();                                // the previous tile's patch is consumed (this tile's loads are already in flight)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + 256 * it;
+        if (i < NPX) {
+            const f32x4 a0 = xv[it][0], a1 = xv[it][1], c0v = xv[it][2], c1v = xv[it][3];
+            *reinterpret_cast<LV8*>(patch + i * 16) = LV8{(LT)a0[0], (LT)a0[1], (LT)a0[2], (LT)a0[3], (LT)a1[0], (LT)a1[1], (LT)a1[2], (LT)a1[3]};
+            *reinterpret_cast<LV8*>(patch + i * 16 + 8) = LV8{(LT)c0v[0], (LT)c0v[1], (LT)c0v[2], (LT)c0v[3], (LT)c1v[0], (LT)c1v[1], (LT)c1v[2], (LT)c1v[3]};
+        }
+    }
+    __syncthreads();
+    // wave w: output rows 2 w, 2 w + 1 of the tile, four 16-pixel column tiles each, two tiles per pass
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = 2 * wid + (pass >> 1), colb = (pass & 1) * 32;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { acc[0][u] = b4[0]; acc[1][u] = b4[1]; }
+        const LT* base = patch + (row * LN5_PW + colb + j) * 16;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                LV8 bx[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) bx[u] = *reinterpret_cast<const LV8*>(base + tapoff[g] + (16 * u) * 16 + 8 * t);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if constexpr (PREC == 1) acc[rt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[g][t][rt], bx[u], acc[rt][u], 0, 0, 0);
+                        else acc[rt][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aw[g][t][rt], bx[u], acc[rt][u], 0, 0, 0);
+                    }
+            }
+        // lane (pixel j, row group kg): channels 4 kg .. 4 kg + 3 of row tile 0, 16 .. 19 of row tile 1 (kg = 0)
+        const int ho = r0 + row;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int wo = c0 + colb + 16 * u + j;
+            if (ho < p.Ho && wo < p.Wo) {
+                const size_t m = ((size_t)b * p.Ho + ho) * p.Wo + wo;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[0][u][r], p.act, p.alpha);
+                *reinterpret_cast<f32x4*>(p.y + m * 20 + 4 * kg) = v;
+                if (kg == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[1][u][r], p.act, p.alpha);
+                    *reinterpret_cast<f32x4*>(p.y + m * 20 + 16) = v;
+                }
+            }
+        }
+    }
+    }
+}
+
 static bool s2k3c9_geometry(const ConvParams& p) {
     return p.KH == 3 && p.KW == 3 && p.stride == 2 && p.pad_h == 0 && p.pad_w == 0 && !p.ups && p.io == 0 && p.C1 == 8 && p.C2 == 1 && p.Cout == 16 &&
            p.Ho == (p.H - 3) / 2 + 1 && p.Wo == (p.W - 3) / 2 + 1 && p.H >= 3 && p.W >= 3 && (long)p.B * p.H * p.W * 8 * 4 < (1L << 31) - 64 &&
@@ -203,6 +322,17 @@ static int s2conv_dispatch(const ConvParams& p, hipStream_t st) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(s2k3c9_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
         MMSEG_SET_LAST(21, 16, 16);
+        return MMSEG_CHECK_LAUNCH();
+    }
+    // the localisation network's first layer (forward, 16-bit modes)
+    if (!p.transposed && plain && p.y2 == nullptr && p.w != nullptr && g_conv_bf16 != 0 && p.KH == 5 && p.KW == 5 && p.stride == 1 && p.pad_h == 0 &&
+        p.pad_w == 0 && !p.ups && p.io == 0 && p.C1 == 8 && p.C2 == 8 && p.Cout == 20 && p.Ho == p.H - 4 && p.Wo == p.W - 4 && p.H >= 5 && p.W >= 5 &&
+        aligned16(p.x1) && aligned16(p.x2) && aligned16(p.y) && (p.bias == nullptr || aligned16(p.bias)) && (long)p.B * p.H * p.W * 32 < (1L << 31) - 64) {
+        long blocks = (long)p.B * ((p.Ho + LN5_TH - 1) / LN5_TH) * ((p.Wo + LN5_TW - 1) / LN5_TW);
+        if (blocks > 512) blocks = 512;                 // two blocks per CU, each walking tiles with a stride of the grid
+        if (g_conv_bf16 == 1) hipLaunchKernelGGL((locnet5_fwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((locnet5_fwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        MMSEG_SET_LAST(23, 16, 20);
         return MMSEG_CHECK_LAUNCH();
     }
     // the data gradient arrives as a fractionally strided launch over dy: 16 input channels, 9 outputs split 8 + 1, padding K - 1

@@ -647,3 +647,29 @@ def test_node_of_the_8_channel_conv_uses_the_one_launch_kernel_and_matches_the_i
         assert float((d > 0).float().mean()) < 0.01       # (a 16-bit rounding flips only where the fp32 sums straddle a tie)
     finally:
         N.call('mmseg_conv16_mode', prev)
+
+
+@pytest.mark.parametrize('B,H,W,act', [(2, 20, 23, 2), (1, 64, 64, 2), (3, 9, 12, 0), (1, 5, 5, 2)])
+def test_locnet_first_layer_in_the_16bit_modes(B, H, W, act, mode):
+    """locnet5_fwd_kernel (s2conv.hpp): Conv2D(20, 5, 'valid') + LeakyReLU(0.3) over Concatenate([anatomy 1, anatomy 2]) (stn_spline.py:98-103) --
+    fp32 tensors, operands rounded to the 16-bit type on the way into v_mfma_f32_16x16x32_*: against the fp64 oracle on the rounded operands
+    (exact products, fp32 sums), pixel counts that fill neither the last 16-pixel tile nor the last pass of two tiles"""
+    from oracle import ops as O
+    x1 = rnd(B, H, W, 8, seed=1).to(DEV)
+    x2 = rnd(B, H, W, 8, seed=2).to(DEV)
+    w = (rnd(5, 5, 16, 20, seed=3) * (2.0 / 400) ** 0.5).to(DEV)
+    b = rnd(20, seed=4).to(DEV)
+    Ho, Wo = H - 4, W - 4
+    y = torch.full((B, Ho, Wo, 20), float('nan'), device=DEV)
+    N.call('mmseg_conv2d_fwd', x1, x2, w, None, b, y, None, B, H, W, 8, 8, Ho, Wo, 20, 5, 5, 1, 0, 0, 0, 0, act, 0.3, 0)
+    assert N.call('mmseg_conv2d_last_kernel') // 1000000 == 23
+    assert not torch.isnan(y).any()
+    xin = torch.cat([x1.to(mode).float().cpu().double(), x2.to(mode).float().cpu().double()], -1)
+    ref = O.conv2d(xin, w.to(mode).float().cpu().double(), b.cpu().double(), padding='valid')
+    ref = O.leaky_relu(ref, 0.3) if act == 2 else ref
+    err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, err
+    # without a bias
+    N.call('mmseg_conv2d_fwd', x1, x2, w, None, None, y, None, B, H, W, 8, 8, Ho, Wo, 20, 5, 5, 1, 0, 0, 0, 0, 0, 0.0, 0)
+    ref0 = O.conv2d(xin, w.to(mode).float().cpu().double(), None, padding='valid')
+    assert float((y.cpu().double() - ref0).abs().max()) <= 2e-5 * float(ref0.abs().max())
