@@ -45,7 +45,7 @@ _FAMILY = {1: 'conv_fast_kernel', 2: 'conv_fwd_kernel', 3: 'conv_direct_kernel',
            13: 'smallk_wgrad_kernel', 22: 's2k3c9_wgrad_kernel'}
 HBM_BOUND_FAMILIES = ('pw_reduce_kernel', 'smallk_conv_kernel', 'pw_reduce_wgrad_kernel', 'smallk_wgrad_kernel', 'conv_direct_kernel', 'conv_direct_mfma_kernel',
                       'conv_wgrad_c8m_kernel', 'conv_dgrad_s2k4_smallc_kernel', 'conv8h_kernel', 's2k3c9_fwd_kernel', 's2k3c9_dgrad_kernel',
-                      's2k3c9_wgrad_kernel', 'locnet5_fwd_kernel')
+                      's2k3c9_wgrad_kernel', 'locnet5_fwd_kernel')      # (locnet5_f32_kernel is MFMA-bound: priced against the fp32 peak)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s
 
 
@@ -57,7 +57,10 @@ def kernel_name(kid, prec):
     if fam == 19:
         return 'wgrad16h_kernel<%d>' % prec
     if fam == 23:              # the localisation network's first layer in the 16-bit modes (csrc/s2conv.hpp)
-        return 'locnet5_fwd_kernel<%d>' % prec
+        cin, cout = rest // 1000, rest % 1000
+        if prec and cin == 16 and cout == 20:
+            return 'locnet5_fwd_kernel<%d>' % prec          # (a padded launch of this shape would be the fp32 kernel; the models have none)
+        return 'locnet5_f32_kernel<%s, %d>' % ('8, 8' if cin == 16 else '20, 0', cout)
     if fam == 21:              # the modality encoder's first layer (csrc/s2conv.hpp): N field 16 = forward, 9 = data gradient
         return 's2k3c9_fwd_kernel' if rest % 1000 == 16 else 's2k3c9_dgrad_kernel'
     if fam == 20:              # <precision, column tiles per wave, 16-bit input, 16-bit output, ReLU>: the M tile field carries the three flags

@@ -306,6 +306,92 @@ __global__ __launch_bounds__(256, 2) void locnet5_fwd_kernel(ConvParams p) {
     }
 }
 
+// The 5 x 5 layers of the localisation network in fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products like every fp32 kernel of the library):
+// <8, 8, 20> the first layer, <20, 0, 20> the second and third (stn_spline.py:104-109) and their data gradients (padding 4, flipped kernel),
+// <20, 0, 16> the first layer's data gradient (its 16 outputs go to the two anatomies' gradients, 8 + 8).  25 taps x CT / 4 k-steps, lane
+// (pixel, kq) supplies channel 4 q + kq.  Two row tiles (20 outputs): wave w owns row tile w & 1 and half of the tile's 32 pixel groups; one
+// row tile (16 outputs): a quarter each.  The wave's weight values (100 / 125) stay in registers; the patch sits in LDS in fp32 with an 80-byte
+// pixel pitch (the 16 pixels of a read then cover the 64 banks once; 64 bytes would put pixels j and j + 4 on one bank).  MFMA-bound: 32 cycles
+// per k-step, 16 pixels and row tile (the second row tile multiplies 12 rows of zeros).
+template <int CA, int CB, int NOUT>
+__global__ __launch_bounds__(256, 2) void locnet5_f32_kernel(ConvParams p) {
+    constexpr int PP = 20, CT = CA + CB, NQ = CT / 4, NRT = (NOUT + 15) / 16;
+    static_assert(CT <= PP && CT % 4 == 0 && CA % 4 == 0 && NOUT % 4 == 0, "channel quads");
+    __shared__ __attribute__((aligned(16))) float patch[LN5_PH * LN5_PW * PP];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int rt = NRT == 2 ? (wid & 1) : 0, part = NRT == 2 ? (wid >> 1) : wid;
+    constexpr int NGRP = NRT == 2 ? 8 : 4;          // passes (of two 16-pixel groups) per wave and tile
+    const int tw = (p.Wo + LN5_TW - 1) / LN5_TW, th = (p.Ho + LN5_TH - 1) / LN5_TH;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H * p.W * CA * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(CB ? p.x2 : p.x1), 0, CB ? p.B * p.H * p.W * CB * 4 : 0, 0x00020000);
+    constexpr int NPX = LN5_PH * LN5_PW, NIT = (NPX + 255) / 256;
+    // A operand of this wave's row tile: k-step (tap, q) -> w[tap][4 q + kq][16 rt + j]
+    float aw[25][NQ];
+    const int n = 16 * rt + j;
+#pragma unroll
+    for (int tap = 0; tap < 25; ++tap)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) aw[tap][q] = n < NOUT ? p.w[(tap * CT + 4 * q + kq) * NOUT + n] : 0.f;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && 16 * rt + 4 * kq < NOUT) b4 = *reinterpret_cast<const f32x4*>(p.bias + 16 * rt + 4 * kq);
+    for (int bid = (int)blockIdx.x; bid < p.B * tw * th; bid += (int)gridDim.x) {
+        const int b = bid / (tw * th), tr = bid - b * (tw * th), ty = tr / tw, tx = tr - ty * tw;
+        const int r0 = ty * LN5_TH, c0 = tx * LN5_TW;
+        f32x4 xv[NIT][NQ];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            const int pr = i / LN5_PW, pc = i - pr * LN5_PW;
+            const int hi = r0 + pr - p.pad_h, wi = c0 + pc - p.pad_w;
+            const bool ok = i < NPX && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int pix = (b * p.H + hi) * p.W + wi;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                xv[it][q] = 4 * q < CA ? buf_load4(r1, ok ? (pix * CA + 4 * q) * 4 : BUF_OOB) : buf_load4(r2, ok ? (pix * CB + 4 * q - CA) * 4 : BUF_OOB);
+        }
+        __syncthreads();                            // the previous tile's patch is consumed (this tile's loads are already in flight)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            if (i < NPX) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(patch + i * PP + 4 * q) = xv[it][q];
+            }
+        }
+        __syncthreads();
+        // two 16-pixel groups per pass (two independent accumulator chains)
+#pragma unroll 1
+        for (int gq = 0; gq < NGRP; ++gq) {
+            const int row = (LN5_TH / (NRT == 2 ? 2 : 4)) * part + (gq >> 1), col = (gq & 1) * 32;
+            const float* base = patch + (row * LN5_PW + col + j) * PP + kq;
+            f32x4 acc[2] = {b4, b4};
+#pragma unroll
+            for (int tap = 0; tap < 25; ++tap)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        acc[u] = s2_mfma(aw[tap][q], base[((tap / 5) * LN5_PW + (tap % 5) + 16 * u) * PP + 4 * q], acc[u]);
+            // lane (pixel j, row group kq): channels 16 rt + 4 kq .. + 3
+            const int ho = r0 + row, ch = 16 * rt + 4 * kq;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int wo = c0 + col + 16 * u + j;
+                if (ho < p.Ho && wo < p.Wo && ch < NOUT) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_apply(acc[u][r], p.act, p.alpha);
+                    const size_t m = ((size_t)b * p.Ho + ho) * p.Wo + wo;
+                    if (p.y2 == nullptr) *reinterpret_cast<f32x4*>(p.y + m * NOUT + ch) = v;
+                    else if (ch < p.nsplit1) *reinterpret_cast<f32x4*>(p.y + m * p.nsplit1 + ch) = v;
+                    else *reinterpret_cast<f32x4*>(p.y2 + m * (NOUT - p.nsplit1) + (ch - p.nsplit1)) = v;
+                }
+            }
+        }
+    }
+}
+
 static bool s2k3c9_geometry(const ConvParams& p) {
     return p.KH == 3 && p.KW == 3 && p.stride == 2 && p.pad_h == 0 && p.pad_w == 0 && !p.ups && p.io == 0 && p.C1 == 8 && p.C2 == 1 && p.Cout == 16 &&
            p.Ho == (p.H - 3) / 2 + 1 && p.Wo == (p.W - 3) / 2 + 1 && p.H >= 3 && p.W >= 3 && (long)p.B * p.H * p.W * 8 * 4 < (1L << 31) - 64 &&
@@ -324,16 +410,27 @@ static int s2conv_dispatch(const ConvParams& p, hipStream_t st) {
         MMSEG_SET_LAST(21, 16, 16);
         return MMSEG_CHECK_LAUNCH();
     }
-    // the localisation network's first layer (forward, 16-bit modes)
-    if (!p.transposed && plain && p.y2 == nullptr && p.w != nullptr && g_conv_bf16 != 0 && p.KH == 5 && p.KW == 5 && p.stride == 1 && p.pad_h == 0 &&
-        p.pad_w == 0 && !p.ups && p.io == 0 && p.C1 == 8 && p.C2 == 8 && p.Cout == 20 && p.Ho == p.H - 4 && p.Wo == p.W - 4 && p.H >= 5 && p.W >= 5 &&
-        aligned16(p.x1) && aligned16(p.x2) && aligned16(p.y) && (p.bias == nullptr || aligned16(p.bias)) && (long)p.B * p.H * p.W * 32 < (1L << 31) - 64) {
-        long blocks = (long)p.B * ((p.Ho + LN5_TH - 1) / LN5_TH) * ((p.Wo + LN5_TW - 1) / LN5_TW);
-        if (blocks > 512) blocks = 512;                 // two blocks per CU, each walking tiles with a stride of the grid
-        if (g_conv_bf16 == 1) hipLaunchKernelGGL((locnet5_fwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((locnet5_fwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-        MMSEG_SET_LAST(23, 16, 20);
-        return MMSEG_CHECK_LAUNCH();
+    // the localisation network's 5 x 5 layers and their data gradients (the first layer's forward pass on 16-bit MFMA operands in the 16-bit
+    // modes, everything else on the fp32 MFMA)
+    if (!p.transposed && plain && p.w != nullptr && p.KH == 5 && p.KW == 5 && p.stride == 1 && p.pad_h == p.pad_w && (p.pad_h == 0 || p.pad_h == 4) &&
+        !p.ups && p.io == 0 && p.Ho == p.H + 2 * p.pad_h - 4 && p.Wo == p.W + 2 * p.pad_w - 4 && p.Ho >= 1 && p.Wo >= 1 &&
+        aligned16(p.x1) && (p.C2 == 0 || aligned16(p.x2)) && aligned16(p.y) && (p.y2 == nullptr || aligned16(p.y2)) && aligned16(p.w) &&
+        (p.bias == nullptr || aligned16(p.bias)) && (long)p.B * p.H * p.W * 80 < (1L << 31) - 64) {
+        const int shape = (p.C1 == 8 && p.C2 == 8 && p.Cout == 20 && p.y2 == nullptr) ? 1
+                        : (p.C1 == 20 && p.C2 == 0 && p.Cout == 20 && p.y2 == nullptr) ? 2
+                        : (p.C1 == 20 && p.C2 == 0 && p.Cout == 16 && (p.y2 == nullptr || p.nsplit1 == 8)) ? 3 : 0;
+        if (shape) {
+            long blocks = (long)p.B * ((p.Ho + LN5_TH - 1) / LN5_TH) * ((p.Wo + LN5_TW - 1) / LN5_TW);
+            if (blocks > 512) blocks = 512;             // two blocks per CU, each walking tiles with a stride of the grid
+            const dim3 grid((unsigned)blocks), blk(256);
+            if (shape == 1 && p.pad_h == 0 && g_conv_bf16 == 1) hipLaunchKernelGGL((locnet5_fwd_kernel<1>), grid, blk, 0, st, p);
+            else if (shape == 1 && p.pad_h == 0 && g_conv_bf16 == 2) hipLaunchKernelGGL((locnet5_fwd_kernel<2>), grid, blk, 0, st, p);
+            else if (shape == 1) hipLaunchKernelGGL((locnet5_f32_kernel<8, 8, 20>), grid, blk, 0, st, p);
+            else if (shape == 2) hipLaunchKernelGGL((locnet5_f32_kernel<20, 0, 20>), grid, blk, 0, st, p);
+            else hipLaunchKernelGGL((locnet5_f32_kernel<20, 0, 16>), grid, blk, 0, st, p);
+            MMSEG_SET_LAST(23, p.C1 + p.C2, p.Cout);
+            return MMSEG_CHECK_LAUNCH();
+        }
     }
     // the data gradient arrives as a fractionally strided launch over dy: 16 input channels, 9 outputs split 8 + 1, padding K - 1
     if (p.transposed && plain && p.w != nullptr && p.KH == 3 && p.KW == 3 && p.stride == 2 && p.pad_h == 2 && p.pad_w == 2 && !p.ups && p.io == 0 &&

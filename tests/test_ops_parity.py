@@ -98,6 +98,10 @@ CONV_CASES = [
     (2, 16, 16, 64, 0, 128, 4, 2, 'valid', 'leaky', False),
     (2, 9, 9, 64, 0, 128, 4, 1, 'valid', 'leaky', False),
     (2, 20, 20, 8, 8, 20, 5, 1, 'valid', 'leaky', False),
+    (3, 9, 12, 8, 8, 20, 5, 1, 'valid', 'leaky', False),       # locnet first layer (s2conv.hpp): less than one tile, batch 3
+    (1, 40, 70, 8, 8, 20, 5, 1, 'valid', None, False),         # ... several tiles, the last column tile partly outside the image
+    (2, 18, 22, 20, 0, 20, 5, 1, 'valid', 'leaky', False),     # locnet second / third layer and its data gradient (padding 4, flipped kernel)
+    (1, 13, 80, 20, 0, 20, 5, 1, 'valid', 'leaky', False),     # ... two column tiles, two row tiles
     (2, 16, 16, 64, 0, 8, 1, 1, 'same', None, False),
     (2, 16, 16, 64, 0, 5, 1, 1, 'same', None, False),
     (2, 16, 16, 8, 0, 1, 1, 1, 'same', 'tanh', False),
