@@ -60,7 +60,7 @@ def kernel_name(kid, prec):
         cin, cout = rest // 1000, rest % 1000
         if prec and cin == 16 and cout == 20:
             return 'locnet5_fwd_kernel<%d>' % prec          # (a padded launch of this shape would be the fp32 kernel; the models have none)
-        return 'locnet5_f32_kernel<%s, %d>' % ('8, 8' if cin == 16 else '20, 0', cout)
+        return 'locnet5_f32_kernel<%s, %d, %d>' % ('8, 8' if cin == 16 else '20, 0', cout, prec)
     if fam == 21:              # the modality encoder's first layer (csrc/s2conv.hpp): N field 16 = forward, 9 = data gradient
         return 's2k3c9_fwd_kernel' if rest % 1000 == 16 else 's2k3c9_dgrad_kernel'
     if fam == 20:              # <precision, column tiles per wave, 16-bit input, 16-bit output, ReLU>: the M tile field carries the three flags

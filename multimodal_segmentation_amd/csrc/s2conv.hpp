@@ -307,13 +307,19 @@ __global__ __launch_bounds__(256, 2) void locnet5_fwd_kernel(ConvParams p) {
 }
 
 // The 5 x 5 layers of the localisation network in fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products like every fp32 kernel of the library):
-// <8, 8, 20> the first layer, <20, 0, 20> the second and third (stn_spline.py:104-109) and their data gradients (padding 4, flipped kernel),
+// <8, 8, 20, .> the first layer, <20, 0, 20, .> the second and third (stn_spline.py:104-109) and their data gradients (padding 4, flipped kernel),
 // <20, 0, 16> the first layer's data gradient (its 16 outputs go to the two anatomies' gradients, 8 + 8).  25 taps x CT / 4 k-steps, lane
 // (pixel, kq) supplies channel 4 q + kq.  Two row tiles (20 outputs): wave w owns row tile w & 1 and half of the tile's 32 pixel groups; one
 // row tile (16 outputs): a quarter each.  The wave's weight values (100 / 125) stay in registers; the patch sits in LDS in fp32 with an 80-byte
 // pixel pitch (the 16 pixels of a read then cover the 64 banks once; 64 bytes would put pixels j and j + 4 on one bank).  MFMA-bound: 32 cycles
 // per k-step, 16 pixels and row tile (the second row tile multiplies 12 rows of zeros).
-template <int CA, int CB, int NOUT>
+// PREC != 0 (16-bit modes): the operands are rounded to the mode's 16-bit type exactly where the generic kernel's 16-bit instance -- which these
+// launches used to run on -- rounded them (activations and weights of forward and stride-1 data-gradient launches); products and sums stay fp32.
+template <int PREC> __device__ __forceinline__ float ln5_round(float v) {
+    if constexpr (PREC == 0) return v;
+    else return (float)(typename LowPrec<PREC>::T)v;
+}
+template <int CA, int CB, int NOUT, int PREC>
 __global__ __launch_bounds__(256, 2) void locnet5_f32_kernel(ConvParams p) {
     constexpr int PP = 20, CT = CA + CB, NQ = CT / 4, NRT = (NOUT + 15) / 16;
     static_assert(CT <= PP && CT % 4 == 0 && CA % 4 == 0 && NOUT % 4 == 0, "channel quads");
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void locnet5_f32_kernel(ConvParams p) {
 #pragma unroll
     for (int tap = 0; tap < 25; ++tap)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) aw[tap][q] = n < NOUT ? p.w[(tap * CT + 4 * q + kq) * NOUT + n] : 0.f;
+        for (int q = 0; q < NQ; ++q) aw[tap][q] = n < NOUT ? ln5_round<PREC>(p.w[(tap * CT + 4 * q + kq) * NOUT + n]) : 0.f;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && 16 * rt + 4 * kq < NOUT) b4 = *reinterpret_cast<const f32x4*>(p.bias + 16 * rt + 4 * kq);
     for (int bid = (int)blockIdx.x; bid < p.B * tw * th; bid += (int)gridDim.x) {
@@ -356,7 +362,10 @@ __global__ __launch_bounds__(256, 2) void locnet5_f32_kernel(ConvParams p) {
             const int i = tid + 256 * it;
             if (i < NPX) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(patch + i * PP + 4 * q) = xv[it][q];
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 v = xv[it][q];
+                    *reinterpret_cast<f32x4*>(patch + i * PP + 4 * q) = f32x4{ln5_round<PREC>(v[0]), ln5_round<PREC>(v[1]), ln5_round<PREC>(v[2]), ln5_round<PREC>(v[3])};
+                }
             }
         }
         __syncthreads();
@@ -425,9 +434,13 @@ static int s2conv_dispatch(const ConvParams& p, hipStream_t st) {
             const dim3 grid((unsigned)blocks), blk(256);
             if (shape == 1 && p.pad_h == 0 && g_conv_bf16 == 1) hipLaunchKernelGGL((locnet5_fwd_kernel<1>), grid, blk, 0, st, p);
             else if (shape == 1 && p.pad_h == 0 && g_conv_bf16 == 2) hipLaunchKernelGGL((locnet5_fwd_kernel<2>), grid, blk, 0, st, p);
-            else if (shape == 1) hipLaunchKernelGGL((locnet5_f32_kernel<8, 8, 20>), grid, blk, 0, st, p);
-            else if (shape == 2) hipLaunchKernelGGL((locnet5_f32_kernel<20, 0, 20>), grid, blk, 0, st, p);
-            else hipLaunchKernelGGL((locnet5_f32_kernel<20, 0, 16>), grid, blk, 0, st, p);
+#define LN5(CA, CB, NO) do { if (g_conv_bf16 == 1) hipLaunchKernelGGL((locnet5_f32_kernel<CA, CB, NO, 1>), grid, blk, 0, st, p);         \
+                             else if (g_conv_bf16 == 2) hipLaunchKernelGGL((locnet5_f32_kernel<CA, CB, NO, 2>), grid, blk, 0, st, p);    \
+                             else hipLaunchKernelGGL((locnet5_f32_kernel<CA, CB, NO, 0>), grid, blk, 0, st, p); } while (0)
+            else if (shape == 1) LN5(8, 8, 20);
+            else if (shape == 2) LN5(20, 0, 20);
+            else LN5(20, 0, 16);
+#undef LN5
             MMSEG_SET_LAST(23, p.C1 + p.C2, p.Cout);
             return MMSEG_CHECK_LAUNCH();
         }

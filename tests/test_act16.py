@@ -673,3 +673,23 @@ def test_locnet_first_layer_in_the_16bit_modes(B, H, W, act, mode):
     N.call('mmseg_conv2d_fwd', x1, x2, w, None, None, y, None, B, H, W, 8, 8, Ho, Wo, 20, 5, 5, 1, 0, 0, 0, 0, 0, 0.0, 0)
     ref0 = O.conv2d(xin, w.to(mode).float().cpu().double(), None, padding='valid')
     assert float((y.cpu().double() - ref0).abs().max()) <= 2e-5 * float(ref0.abs().max())
+
+
+@pytest.mark.parametrize('B,H,W,C,Cout,pad,split', [(2, 18, 22, 20, 20, 0, False), (1, 13, 80, 20, 20, 4, False), (2, 16, 19, 20, 16, 4, True)])
+def test_locnet_other_layers_round_their_operands_in_the_16bit_modes(B, H, W, C, Cout, pad, split, mode):
+    """locnet5_f32_kernel<..., PREC> (s2conv.hpp): the second / third 5 x 5 layer, its data gradient (padding 4) and the first layer's data
+    gradient (16 outputs written to two 8-channel tensors) multiply on the fp32 MFMA in every mode; in the 16-bit modes their operands are
+    rounded where the generic kernel's 16-bit instance rounded them -- against the fp64 oracle on the rounded operands"""
+    from oracle import ops as O
+    x = rnd(B, H, W, C, seed=1).to(DEV)
+    w = (rnd(5, 5, C, Cout, seed=2) * (2.0 / (25 * C)) ** 0.5).to(DEV)
+    Ho, Wo = H + 2 * pad - 4, W + 2 * pad - 4
+    y = torch.full((B, Ho, Wo, 8 if split else Cout), float('nan'), device=DEV)
+    y2 = torch.full((B, Ho, Wo, Cout - 8), float('nan'), device=DEV) if split else None
+    N.call('mmseg_conv2d_fwd', x, None, w, None, None, y, y2, B, H, W, C, 0, Ho, Wo, Cout, 5, 5, 1, pad, pad, 0, 0, 0, 0.0, 8 if split else 0)
+    assert N.call('mmseg_conv2d_last_kernel') // 1000000 == 23
+    xin = torch.nn.functional.pad(x.to(mode).float().cpu().double(), (0, 0, pad, pad, pad, pad))
+    ref = O.conv2d(xin, w.to(mode).float().cpu().double(), None, padding='valid')
+    out = torch.cat([y, y2], -1) if split else y
+    assert not torch.isnan(out).any()
+    assert float((out.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
