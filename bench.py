@@ -42,7 +42,7 @@ TFLOP_PER_PAIR = {('film', 256): 1.630, ('spade', 256): 2.871, ('mmsdnet', 256):
 _FAMILY = {1: 'conv_fast_kernel', 2: 'conv_fwd_kernel', 3: 'conv_direct_kernel', 4: 'conv_fast_batched_kernel',
            5: 'conv_dgrad_s2k4_smallc_kernel', 6: 'conv_wgrad_tr_kernel', 7: 'conv_wgrad_fast_kernel', 8: 'conv_wgrad_kernel',
            9: 'conv_wgrad_c8m_kernel', 10: 'pw_reduce_kernel', 11: 'smallk_conv_kernel', 12: 'pw_reduce_wgrad_kernel',
-           13: 'smallk_wgrad_kernel', 22: 's2k3c9_wgrad_kernel'}
+           13: 'smallk_wgrad_kernel', 22: 's2k3c9_wgrad_kernel', 24: 'locnet5_wgrad_kernel'}
 HBM_BOUND_FAMILIES = ('pw_reduce_kernel', 'smallk_conv_kernel', 'pw_reduce_wgrad_kernel', 'smallk_wgrad_kernel', 'conv_direct_kernel', 'conv_direct_mfma_kernel',
                       'conv_wgrad_c8m_kernel', 'conv_dgrad_s2k4_smallc_kernel', 'conv8h_kernel', 's2k3c9_fwd_kernel', 's2k3c9_dgrad_kernel',
                       's2k3c9_wgrad_kernel', 'locnet5_fwd_kernel')      # (locnet5_f32_kernel is MFMA-bound: priced against the fp32 peak)

@@ -781,7 +781,7 @@ static int g_conv_bf16 = 0;     // 0 fp32, 1 bf16, 2 fp16
 // M tile * 1000 + N tile (flag: 16-byte gather of the generic kernels / 16-bit input of the fast kernels / two inputs of conv_wgrad_tr_kernel); families: 1 conv_fast_kernel, 2 conv_fwd_kernel (generic), 3 conv_direct_kernel, 4 conv_fast_batched_kernel,
 // 5 conv_dgrad_s2k4_smallc_kernel, 6 conv_wgrad_tr_kernel, 7 conv_wgrad_fast_kernel, 8 conv_wgrad_kernel, 9 conv_wgrad_c8_kernel,
 // 10 pw_reduce_kernel<LANES, COUT, VPL>, 12 pw_reduce_wgrad_kernel<...> (M tile field = LANES, N tile field = COUT);
-// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv_wgrad_tr_anyw_kernel; 16 conv16_kernel, 17 conv16h_kernel (M tile field = pixels per block), 18 wgrad32h_kernel<NCI, NCO>, 19 wgrad16h_kernel, 20 conv8h_kernel (M tile field = 16-bit x | 2 * 16-bit y | 4 * ReLU); 21 s2k3c9_fwd_kernel (N field 16) / s2k3c9_dgrad_kernel (N field 9), 22 s2k3c9_wgrad_kernel, 23 locnet5_fwd_kernel
+// 11 smallk_conv_kernel<KS, CIN, L>, 13 smallk_wgrad_kernel<...> (M tile field = KS * 20 + L, N tile field = CIN); 14 conv_wgrad_tr_anyw_kernel; 16 conv16_kernel, 17 conv16h_kernel (M tile field = pixels per block), 18 wgrad32h_kernel<NCI, NCO>, 19 wgrad16h_kernel, 20 conv8h_kernel (M tile field = 16-bit x | 2 * 16-bit y | 4 * ReLU); 21 s2k3c9_fwd_kernel (N field 16) / s2k3c9_dgrad_kernel (N field 9), 22 s2k3c9_wgrad_kernel, 23 locnet5_fwd_kernel / locnet5_f32_kernel, 24 locnet5_wgrad_kernel
 static int g_last_kernel = 0;
 #define MMSEG_SET_LAST(fam, bm, bn) (g_last_kernel = (fam) * 1000000 + (bm) * 1000 + (bn))
 template <int BM, int BN, int WM, int WN, int PREC = 0, bool IN16 = false>
@@ -2558,6 +2558,11 @@ long mmseg_conv2d_wgrad_workspace(int B, int Ho, int Wo, int Cin, int Cout, int 
         const long need_h = wgrad_ws_floats(Sh, K * Cout);
         if (need_h > need) need = need_h;
     }
+    if (KH == 5 && KW == 5 && Cin == 16 && Cout == 20) {
+        // the localisation network's first layer (s2conv.hpp: locnet5_wgrad_kernel): one slab per block, at most 512 blocks
+        const long need_l = wgrad_ws_floats(512, K * Cout);
+        if (need_l > need) need = need_l;
+    }
     return need;
 }
 
@@ -2726,6 +2731,16 @@ static int conv2d_wgrad_impl(const float* x1, const float* x2, const float* dy, 
             hipLaunchKernelGGL(s2k3c9_wgrad_kernel, dim3(nblk), dim3(256), 0, st, p, dy, ws, steps);
             MMSEG_SET_LAST(22, 16, 16);
             launched = 1;
+        }
+        if (!launched && s2_on && locnet5_wgrad_geometry(p) && aligned16(x1) && aligned16(x2) && aligned16(dy)) {
+            long nb = (long)p.B * ((p.Ho + LW5_TH - 1) / LW5_TH) * ((p.Wo + LW5_TW - 1) / LW5_TW);
+            if (nb > LW5_MAX_SLABS) nb = LW5_MAX_SLABS;
+            if (wgrad_ws_floats(nb, KN) <= ws_floats) {
+                nblk = (int)nb;
+                hipLaunchKernelGGL(locnet5_wgrad_kernel, dim3(nblk), dim3(256), 0, st, p, dy, ws);
+                MMSEG_SET_LAST(24, 16, 20);
+                launched = 1;
+            }
         }
         if (launched) {
             float* tmp2 = (nblk > 64) ? ws + (size_t)nblk * KN : nullptr;

@@ -401,6 +401,102 @@ __global__ __launch_bounds__(256, 2) void locnet5_f32_kernel(ConvParams p) {
     }
 }
 
+// Weight gradient of the localisation network's first layer: dW[tap][c][n] = sum over output pixels of xcat[pixel + tap][c] * dy[pixel][n].
+// v_mfma_f32_16x16x4_f32 with K = 4 consecutive pixels: a tap's 16 input channels are exactly one 16-row tile, the 20 output channels two
+// column tiles; the 25 taps are dealt to the four waves (7 / 6 / 6 / 6: 56 accumulator registers), every wave walks all pixel groups of the
+// block's tile (4 x 64 output pixels: 8 x 68-pixel patch + the dy tile in LDS, both fp32 with an 80-byte pixel pitch).  One slab per block,
+// every element written by its one owner; then the library's fixed-order slab reduction.  fp32 in every mode, like the kernel it replaces.
+constexpr int LW5_TH = 4, LW5_TW = 64, LW5_PW = LW5_TW + 4, LW5_PH = LW5_TH + 4;
+__global__ __launch_bounds__(256, 2) void locnet5_wgrad_kernel(ConvParams p, const float* __restrict__ dy, float* __restrict__ ws) {
+    constexpr int PP = 20, NPX = LW5_PH * LW5_PW, NITX = (NPX + 255) / 256, NT = 7;
+    __shared__ __attribute__((aligned(16))) float patch[NPX * PP];
+    __shared__ __attribute__((aligned(16))) float dyt[LW5_TH * LW5_TW * PP];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int tw = (p.Wo + LW5_TW - 1) / LW5_TW, th = (p.Ho + LW5_TH - 1) / LW5_TH;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.B * p.H * p.W * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x2, 0, p.B * p.H * p.W * 32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, p.M * 80, 0x00020000);
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // this wave's taps: wid, wid + 4, ...; operand offsets (floats) of lane (row / column j, pixel kq of the group)
+    int offa[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = wid + 4 * t;
+        offa[t] = tap < 25 ? ((tap / 5) * LW5_PW + (tap % 5) + kq) * PP + j : -1;
+    }
+    const int offb = kq * PP + j;
+    for (int bid = (int)blockIdx.x; bid < p.B * tw * th; bid += (int)gridDim.x) {
+        const int b = bid / (tw * th), tr = bid - b * (tw * th), ty = tr / tw, tx = tr - ty * tw;
+        const int r0 = ty * LW5_TH, c0 = tx * LW5_TW;
+        f32x4 xv[NITX][4], dv[5];
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+            const int i = tid + 256 * it;
+            const int pr = i / LW5_PW, pc = i - pr * LW5_PW;
+            const int hi = r0 + pr, wi = c0 + pc;
+            const int off = (i < NPX && hi < p.H && wi < p.W) ? ((b * p.H + hi) * p.W + wi) * 32 : BUF_OOB;
+            xv[it][0] = buf_load4(r1, off); xv[it][1] = buf_load4(r1, off == BUF_OOB ? BUF_OOB : off + 16);
+            xv[it][2] = buf_load4(r2, off); xv[it][3] = buf_load4(r2, off == BUF_OOB ? BUF_OOB : off + 16);
+        }
+        {
+            const int pr = tid / LW5_TW, pc = tid - pr * LW5_TW;
+            const int ho = r0 + pr, wo = c0 + pc;
+            const int off = (ho < p.Ho && wo < p.Wo) ? ((b * p.Ho + ho) * p.Wo + wo) * 80 : BUF_OOB;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) dv[q] = buf_load4(rd, off == BUF_OOB ? BUF_OOB : off + 16 * q);
+        }
+        __syncthreads();                            // the previous tile is consumed (this tile's loads are already in flight)
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+            const int i = tid + 256 * it;
+            if (i < NPX) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(patch + i * PP + 4 * q) = xv[it][q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) *reinterpret_cast<f32x4*>(dyt + tid * PP + 4 * q) = dv[q];
+        __syncthreads();
+#pragma unroll 2
+        for (int g = 0; g < LW5_TH * LW5_TW / 4; ++g) {
+            const int row = g / (LW5_TW / 4), col = (g % (LW5_TW / 4)) * 4;
+            const float* pa = patch + (row * LW5_PW + col) * PP;
+            const float* pb = dyt + (row * LW5_TW + col) * PP + offb;
+            const float d0 = pb[0];
+            const float d1v = pb[16];
+            const float d1 = j < 4 ? d1v : 0.f;                               // (columns 20 .. 31 of the second tile do not exist)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (wid + 4 * t < 25) {
+                    const float a = pa[offa[t]];
+                    acc[t][0] = s2_mfma(a, d0, acc[t][0]);
+                    acc[t][1] = s2_mfma(a, d1, acc[t][1]);
+                }
+        }
+    }
+    // lane (column j, row group kq), register r: dW[tap][c = 4 kq + r][n = 16 ct + j]
+    float* slab = ws + (size_t)blockIdx.x * (400 * 20);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = wid + 4 * t;
+        if (tap < 25) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                slab[(tap * 16 + 4 * kq + r) * 20 + j] = acc[t][0][r];
+                if (j < 4) slab[(tap * 16 + 4 * kq + r) * 20 + 16 + j] = acc[t][1][r];
+            }
+        }
+    }
+}
+static bool locnet5_wgrad_geometry(const ConvParams& p) {
+    return p.KH == 5 && p.KW == 5 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && !p.ups && p.io == 0 && p.C1 == 8 && p.C2 == 8 && p.Cout == 20 &&
+           p.Ho == p.H - 4 && p.Wo == p.W - 4 && p.Ho >= 1 && p.Wo >= 1 && (long)p.B * p.H * p.W * 32 < (1L << 31) - 64 && (long)p.M * 80 < (1L << 31) - 64;
+}
+constexpr int LW5_MAX_SLABS = 512;
+
 static bool s2k3c9_geometry(const ConvParams& p) {
     return p.KH == 3 && p.KW == 3 && p.stride == 2 && p.pad_h == 0 && p.pad_w == 0 && !p.ups && p.io == 0 && p.C1 == 8 && p.C2 == 1 && p.Cout == 16 &&
            p.Ho == (p.H - 3) / 2 + 1 && p.Wo == (p.W - 3) / 2 + 1 && p.H >= 3 && p.W >= 3 && (long)p.B * p.H * p.W * 8 * 4 < (1L << 31) - 64 &&
