@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void s2k3c9_wgrad_kernel(ConvParams p, const f
 
 // =====================================================================================================================================
 // First layer of the localisation network of the anatomy fuser: Conv2D(20, 5, padding='valid') + LeakyReLU(0.3) over
-// Concatenate([anatomy 1 (8 channels), anatomy 2 (8 channels)]) (layers/stn_spline.py:98-103 of the reference: `build_locnet`), forward.
+// Concatenate([anatomy 1 (8 channels), anatomy 2 (8 channels)]) (layers/stn_spline.py:102-107 of the reference: `build_locnet`), forward.
 // 16 input channels and 20 outputs fit no tile of the implicit-GEMM kernels (0.21 of the fp32 peak; 69 TFLOP/s with 16-bit operands); the
 // layer reads 16 x 25 values per output pixel that all sit in L1 / L2.  16-bit modes (this kernel; the operands are rounded exactly where
 // the generic kernel's 16-bit instance rounded them): v_mfma_f32_16x16x32_*, rows = output channels (2 tiles of 16: 20 used), columns = 16
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void locnet5_fwd_kernel(ConvParams p) {
 }
 
 // The 5 x 5 layers of the localisation network in fp32 (v_mfma_f32_16x16x4_f32, exact fp32 products like every fp32 kernel of the library):
-// <8, 8, 20, .> the first layer, <20, 0, 20, .> the second and third (stn_spline.py:104-109) and their data gradients (padding 4, flipped kernel),
+// <8, 8, 20, .> the first layer, <20, 0, 20, .> the second and third (stn_spline.py:108-113) and their data gradients (padding 4, flipped kernel),
 // <20, 0, 16> the first layer's data gradient (its 16 outputs go to the two anatomies' gradients, 8 + 8).  25 taps x CT / 4 k-steps, lane
 // (pixel, kq) supplies channel 4 q + kq.  Two row tiles (20 outputs): wave w owns row tile w & 1 and half of the tile's 32 pixel groups; one
 // row tile (16 outputs): a quarter each.  The wave's weight values (100 / 125) stay in registers; the patch sits in LDS in fp32 with an 80-byte

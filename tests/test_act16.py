@@ -651,7 +651,7 @@ def test_node_of_the_8_channel_conv_uses_the_one_launch_kernel_and_matches_the_i
 
 @pytest.mark.parametrize('B,H,W,act', [(2, 20, 23, 2), (1, 64, 64, 2), (3, 9, 12, 0), (1, 5, 5, 2)])
 def test_locnet_first_layer_in_the_16bit_modes(B, H, W, act, mode):
-    """locnet5_fwd_kernel (s2conv.hpp): Conv2D(20, 5, 'valid') + LeakyReLU(0.3) over Concatenate([anatomy 1, anatomy 2]) (stn_spline.py:98-103) --
+    """locnet5_fwd_kernel (s2conv.hpp): Conv2D(20, 5, 'valid') + LeakyReLU(0.3) over Concatenate([anatomy 1, anatomy 2]) (stn_spline.py:102-107) --
     fp32 tensors, operands rounded to the 16-bit type on the way into v_mfma_f32_16x16x32_*: against the fp64 oracle on the rounded operands
     (exact products, fp32 sums), pixel counts that fill neither the last 16-pixel tile nor the last pass of two tiles"""
     from oracle import ops as O
