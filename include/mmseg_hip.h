@@ -232,7 +232,7 @@ int mmseg_act_bwd_bias_t(const void* dy, const void* y, void* dx, float* bias_gr
  * columns 72..95 zero.  A 1x1 fast-path convolution over it (Cin = 96, weights = the Keras kernel read as [72][Cout] + 24 zero rows)
  * is the reduced-precision form of the SPADE units' 8 -> 128 convolution (layers/spade.py:28) */
 int mmseg_im2col8_t(const void* x, void* out, int B, int H, int W, int hx, int hy, void* stream);
-/* Conv2D(Cout, 3, padding='same') of an 8-channel tensor in the 16-bit modes in ONE launch: the shared convolution of a SPADE unit (layers/spade.py:28-29:
+/* Conv2D(Cout, 3, padding='same') of an 8-channel tensor in the 16-bit modes in ONE launch: the shared convolution of a SPADE unit (layers/spade.py:27:
  * anatomy -> 128 hidden channels + ReLU) and the segmentor's first layer (model_components/segmentor.py:16).  x fp32 (hx 0) or the mode's 16-bit type, w the
  * Keras kernel [3,3,8,Cout], y fp32 (hy 0) or 16-bit; W % 32 == 0, Cout % 4 == 0 (% 8 for a 16-bit y); act 0 none, 1 ReLU, 2 LeakyReLU(alpha).  Replaces mmseg_im2col8_t + a 1x1 mmseg_conv2d_fwd_t. */
 int mmseg_conv8h_fwd_t(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, int act, float alpha,

@@ -631,7 +631,7 @@ static int launch_conv16h_prec(const ConvParams& p, int bn, hipStream_t st) {
 
 // =====================================================================================================================================
 // conv8h: Conv2D(Cout, 3, padding='same') of an 8-CHANNEL tensor in the 16-bit modes -- the shared convolution of every SPADE unit
-// (layers/spade.py:28-29 of the reference: the 8-channel anatomy -> 128 hidden channels + ReLU) and the segmentor's first layer.
+// (layers/spade.py:27 of the reference: the 8-channel anatomy -> 128 hidden channels + ReLU) and the segmentor's first layer.
 // Round 2 / 3 ran it as im2col (72 + 24 zero columns per pixel written as 16-bit rows) + a 1x1 product on conv_fast_kernel with three
 // 32-deep K tiles: 0.06 of the MFMA peak, and bound by neither HBM nor the matrix pipe but by the per-block prologue / epilogue of a
 // K = 96 product.  The layer is OUTPUT-WRITE bound (16 - 32 bytes in, 256 bytes out per pixel: ~ 70 FLOP/byte), so:

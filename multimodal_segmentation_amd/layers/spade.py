@@ -33,7 +33,7 @@ def declare_spade_decoder(m, conf):
 
 
 def spade_hidden(m, name, a):
-    """the unit's shared 3x3 convolution + ReLU (layers/spade.py:28-29).  Its 128-channel output is by far the largest tensor of the
+    """the unit's shared 3x3 convolution + ReLU (layers/spade.py:27).  Its 128-channel output is by far the largest tensor of the
     decoder (1.6 GB per unit in fp32 at 256 x 256 with the 48 decoder passes of an iteration batched); with conf.act_storage = 'half' it and its gradient live
     in HBM as 16-bit tensors (the gamma / beta convolutions and their gradients read / write them as such)."""
     import torch
